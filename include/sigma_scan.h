@@ -1,0 +1,147 @@
+/*
+ * sigma_scan.h -- C ABI of libsigma_hip.so: the MI355X (gfx950) selective-scan
+ * operator that replaces the reference's CUDA extension `selective_scan_cuda_core`.
+ *
+ * Drop-in boundary (reference paths relative to /root/reference):
+ *   sigma_selective_scan_fwd  <->  selective_scan_fwd()
+ *       models/encoders/selective_scan/csrc/selective_scan/selective_scan.cpp:165-249
+ *       (pybind `fwd`, :365)
+ *   sigma_selective_scan_bwd  <->  selective_scan_bwd()
+ *       models/encoders/selective_scan/csrc/selective_scan/selective_scan.cpp:251-362
+ *       (pybind `bwd`, :366)
+ *   the parameter blocks mirror SSMParamsBase / SSMParamsBwd
+ *       models/encoders/selective_scan/csrc/selective_scan/selective_scan.h:26-90
+ *       (sizes, raw device pointers, element strides).
+ *
+ * Plain pointers and sizes only -- no torch types.  The callee never allocates
+ * and never synchronises: it enqueues kernels on `stream` (a hipStream_t passed
+ * as void*; NULL = the null stream) of the CURRENT device and returns.
+ * All pointers are device pointers.  Strides are in ELEMENTS (as in the reference,
+ * selective_scan.cpp:87).  The innermost (sequence) stride of u, delta, B, C,
+ * out, dout, du, ddelta, dB, dC must be 1 (selective_scan.cpp:189-190,206-208).
+ *
+ * Return value: 0 on success, a SIGMA_ERR_* code otherwise; the host wrapper
+ * turns non-zero into RuntimeError like TORCH_CHECK does in the reference.
+ * sigma_scan_last_error() returns a thread-local human-readable message.
+ */
+#ifndef SIGMA_SCAN_H_
+#define SIGMA_SCAN_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SIGMA_SCAN_ABI_VERSION 1
+
+/* dtype of u, delta, B, C, out, dout, du, ddelta  (input_t of the reference,
+ * selective_scan.cpp:174: float / half / bfloat16).  A, D, delta_bias, x, dA,
+ * dD, ddelta_bias and the dB/dC accumulators are always float32 (weight_t). */
+enum sigma_dtype {
+    SIGMA_DTYPE_F32 = 0,
+    SIGMA_DTYPE_F16 = 1,
+    SIGMA_DTYPE_BF16 = 2
+};
+
+enum sigma_status {
+    SIGMA_OK = 0,
+    SIGMA_ERR_NULL_ARG = 1,      /* required pointer is NULL */
+    SIGMA_ERR_BAD_SHAPE = 2,     /* sizes violate the reference's TORCH_CHECKs */
+    SIGMA_ERR_BAD_DTYPE = 3,
+    SIGMA_ERR_BAD_STRIDE = 4,
+    SIGMA_ERR_LAUNCH = 5,        /* hip launch error (cf. C10_CUDA_KERNEL_LAUNCH_CHECK) */
+    SIGMA_ERR_NO_DEVICE = 6,
+    SIGMA_ERR_BAD_OPTION = 7
+};
+
+/* The chunk length of the checkpoint tensor x: n_chunks = ceil(seqlen / 2048)
+ * (selective_scan.cpp:225). */
+#define SIGMA_SCAN_CHUNK 2048
+/* dstate limit of the reference (selective_scan.cpp:10,201). */
+#define SIGMA_SCAN_MAX_DSTATE 256
+
+typedef struct sigma_scan_fwd_params {
+    /* sizes */
+    int32_t batch;      /* B            */
+    int32_t dim;        /* K*d_inner    */
+    int32_t seqlen;     /* L            */
+    int32_t dstate;     /* N            */
+    int32_t n_groups;   /* G; row r uses group r / (dim / G) */
+    int32_t n_chunks;   /* ceil(L / 2048); checked */
+    int32_t io_dtype;   /* enum sigma_dtype */
+    int32_t delta_softplus;
+    /* inputs */
+    const void *u;            /* (B, dim, L)        io_dtype */
+    const void *delta;        /* (B, dim, L)        io_dtype */
+    const float *A;           /* (dim, N)           f32      */
+    const void *B;            /* (B, G, N, L)       io_dtype */
+    const void *C;            /* (B, G, N, L)       io_dtype */
+    const float *D;           /* (dim) or NULL      f32      */
+    const float *delta_bias;  /* (dim) or NULL      f32      */
+    /* outputs */
+    void *out;                /* (B, dim, L)        io_dtype */
+    float *x;                 /* (B, dim, n_chunks, 2N) f32 contiguous, or NULL:
+                                 float2[n] = (prod_{l<=end(c)} a[n,l], x[n,end(c)]) */
+    /* element strides */
+    int64_t u_batch_stride, u_d_stride;
+    int64_t delta_batch_stride, delta_d_stride;
+    int64_t A_d_stride, A_dstate_stride;
+    int64_t B_batch_stride, B_group_stride, B_dstate_stride;
+    int64_t C_batch_stride, C_group_stride, C_dstate_stride;
+    int64_t out_batch_stride, out_d_stride;
+} sigma_scan_fwd_params;
+
+typedef struct sigma_scan_bwd_params {
+    sigma_scan_fwd_params fwd;   /* out is unused; x is the tensor saved by fwd
+                                    (may be NULL only when n_chunks == 1, selective_scan.cpp:320) */
+    const void *dout;            /* (B, dim, L)   io_dtype */
+    void *du;                    /* (B, dim, L)   io_dtype, fully written */
+    void *ddelta;                /* (B, dim, L)   io_dtype, fully written */
+    float *dA;                   /* (dim, N)      f32, ACCUMULATED into (caller zeroes, :331) */
+    float *dB;                   /* (B, G, N, L)  f32, ACCUMULATED into (caller zeroes, :332) */
+    float *dC;                   /* (B, G, N, L)  f32, ACCUMULATED into (caller zeroes, :333) */
+    float *dD;                   /* (dim) or NULL f32, ACCUMULATED into */
+    float *ddelta_bias;          /* (dim) or NULL f32, ACCUMULATED into */
+    int64_t dout_batch_stride, dout_d_stride;
+    int64_t du_batch_stride, du_d_stride;
+    int64_t ddelta_batch_stride, ddelta_d_stride;
+    int64_t dA_d_stride, dA_dstate_stride;
+    int64_t dB_batch_stride, dB_group_stride, dB_dstate_stride;
+    int64_t dC_batch_stride, dC_group_stride, dC_dstate_stride;
+} sigma_scan_bwd_params;
+
+/* Forward: out, x <- scan(u, delta, A, B, C, D, delta_bias). */
+int sigma_selective_scan_fwd(const sigma_scan_fwd_params *params, void *stream);
+
+/* Backward: du, ddelta written; dA, dB, dC, dD, ddelta_bias accumulated (+=). */
+int sigma_selective_scan_bwd(const sigma_scan_bwd_params *params, void *stream);
+
+/* Thread-local description of the last non-zero status returned on this thread. */
+const char *sigma_scan_last_error(void);
+
+/* ABI version of the loaded library (== SIGMA_SCAN_ABI_VERSION it was built with). */
+int sigma_scan_abi_version(void);
+
+/* Tuning knobs for benchmarking; 0 restores the built-in heuristic.
+ *   "fwd_items"  items per lane in the forward kernel  (4, 8 or 16)
+ *   "fwd_waves"  rows (= waves) per workgroup, forward  (1,2,4,8,16)
+ *   "bwd_items"  items per lane in the backward kernel (4 or 8)
+ *   "bwd_waves"  rows per workgroup, backward
+ * Returns SIGMA_ERR_BAD_OPTION for unknown names / unsupported values. */
+int sigma_scan_set_option(const char *name, int value);
+int sigma_scan_get_option(const char *name);
+
+/* Launch geometry the heuristic would pick for a problem (for reports/tests):
+ * writes {items_per_lane, waves_per_workgroup, workgroups, lds_bytes} */
+int sigma_scan_fwd_plan(const sigma_scan_fwd_params *params, int32_t plan[4]);
+int sigma_scan_bwd_plan(const sigma_scan_bwd_params *params, int32_t plan[4]);
+
+/* On-device self test of the wave64 DPP scan primitives against a serial loop.
+ * Returns 0 when every lane matches; enqueues on `stream` and synchronises it. */
+int sigma_scan_selftest(void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SIGMA_SCAN_H_ */

@@ -1,0 +1,129 @@
+"""ctypes binding of libsigma_hip.so (C ABI declared in include/sigma_scan.h).
+
+The library is REQUIRED: importing the operator modules without it raises
+``SigmaHipUnavailable`` -- there is no CPU or eager fallback anywhere in the product
+path (the CPU oracle under oracle/ is test infrastructure only).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsigma_hip.so")
+
+SIGMA_SCAN_ABI_VERSION = 1
+SIGMA_SCAN_CHUNK = 2048
+SIGMA_SCAN_MAX_DSTATE = 256
+
+DTYPE_F32, DTYPE_F16, DTYPE_BF16 = 0, 1, 2
+
+
+class SigmaHipUnavailable(RuntimeError):
+    pass
+
+
+class FwdParams(ctypes.Structure):
+    _fields_ = [
+        ("batch", ctypes.c_int32), ("dim", ctypes.c_int32), ("seqlen", ctypes.c_int32),
+        ("dstate", ctypes.c_int32), ("n_groups", ctypes.c_int32), ("n_chunks", ctypes.c_int32),
+        ("io_dtype", ctypes.c_int32), ("delta_softplus", ctypes.c_int32),
+        ("u", ctypes.c_void_p), ("delta", ctypes.c_void_p), ("A", ctypes.c_void_p),
+        ("B", ctypes.c_void_p), ("C", ctypes.c_void_p), ("D", ctypes.c_void_p),
+        ("delta_bias", ctypes.c_void_p),
+        ("out", ctypes.c_void_p), ("x", ctypes.c_void_p),
+        ("u_batch_stride", ctypes.c_int64), ("u_d_stride", ctypes.c_int64),
+        ("delta_batch_stride", ctypes.c_int64), ("delta_d_stride", ctypes.c_int64),
+        ("A_d_stride", ctypes.c_int64), ("A_dstate_stride", ctypes.c_int64),
+        ("B_batch_stride", ctypes.c_int64), ("B_group_stride", ctypes.c_int64), ("B_dstate_stride", ctypes.c_int64),
+        ("C_batch_stride", ctypes.c_int64), ("C_group_stride", ctypes.c_int64), ("C_dstate_stride", ctypes.c_int64),
+        ("out_batch_stride", ctypes.c_int64), ("out_d_stride", ctypes.c_int64),
+    ]
+
+
+class BwdParams(ctypes.Structure):
+    _fields_ = [
+        ("fwd", FwdParams),
+        ("dout", ctypes.c_void_p), ("du", ctypes.c_void_p), ("ddelta", ctypes.c_void_p),
+        ("dA", ctypes.c_void_p), ("dB", ctypes.c_void_p), ("dC", ctypes.c_void_p),
+        ("dD", ctypes.c_void_p), ("ddelta_bias", ctypes.c_void_p),
+        ("dout_batch_stride", ctypes.c_int64), ("dout_d_stride", ctypes.c_int64),
+        ("du_batch_stride", ctypes.c_int64), ("du_d_stride", ctypes.c_int64),
+        ("ddelta_batch_stride", ctypes.c_int64), ("ddelta_d_stride", ctypes.c_int64),
+        ("dA_d_stride", ctypes.c_int64), ("dA_dstate_stride", ctypes.c_int64),
+        ("dB_batch_stride", ctypes.c_int64), ("dB_group_stride", ctypes.c_int64), ("dB_dstate_stride", ctypes.c_int64),
+        ("dC_batch_stride", ctypes.c_int64), ("dC_group_stride", ctypes.c_int64), ("dC_dstate_stride", ctypes.c_int64),
+    ]
+
+
+# every symbol include/sigma_scan.h declares; tests check the library exports all of them
+EXPORTED_SYMBOLS = (
+    "sigma_selective_scan_fwd",
+    "sigma_selective_scan_bwd",
+    "sigma_scan_last_error",
+    "sigma_scan_abi_version",
+    "sigma_scan_set_option",
+    "sigma_scan_get_option",
+    "sigma_scan_fwd_plan",
+    "sigma_scan_bwd_plan",
+    "sigma_scan_selftest",
+)
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+def load() -> ctypes.CDLL:
+    """Load the HIP library or raise loudly.  Never falls back to anything."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SigmaHipUnavailable(
+            f"{LIB_PATH} is missing: build it with `python -m sigma_amd.build` "
+            "(hipcc --offload-arch=gfx950).  sigma_amd has no CPU/eager fallback.")
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:  # e.g. libamdhip64 not found
+        raise SigmaHipUnavailable(f"cannot load {LIB_PATH}: {e}") from e
+    P = ctypes.POINTER
+    lib.sigma_selective_scan_fwd.argtypes = [P(FwdParams), ctypes.c_void_p]
+    lib.sigma_selective_scan_fwd.restype = ctypes.c_int
+    lib.sigma_selective_scan_bwd.argtypes = [P(BwdParams), ctypes.c_void_p]
+    lib.sigma_selective_scan_bwd.restype = ctypes.c_int
+    lib.sigma_scan_last_error.argtypes = []
+    lib.sigma_scan_last_error.restype = ctypes.c_char_p
+    lib.sigma_scan_abi_version.argtypes = []
+    lib.sigma_scan_abi_version.restype = ctypes.c_int
+    lib.sigma_scan_set_option.argtypes = [ctypes.c_char_p, ctypes.c_int]
+    lib.sigma_scan_set_option.restype = ctypes.c_int
+    lib.sigma_scan_get_option.argtypes = [ctypes.c_char_p]
+    lib.sigma_scan_get_option.restype = ctypes.c_int
+    lib.sigma_scan_fwd_plan.argtypes = [P(FwdParams), P(ctypes.c_int32 * 4)]
+    lib.sigma_scan_fwd_plan.restype = ctypes.c_int
+    lib.sigma_scan_bwd_plan.argtypes = [P(BwdParams), P(ctypes.c_int32 * 4)]
+    lib.sigma_scan_bwd_plan.restype = ctypes.c_int
+    lib.sigma_scan_selftest.argtypes = [ctypes.c_void_p]
+    lib.sigma_scan_selftest.restype = ctypes.c_int
+    if lib.sigma_scan_abi_version() != SIGMA_SCAN_ABI_VERSION:
+        raise SigmaHipUnavailable(
+            f"ABI mismatch: library {lib.sigma_scan_abi_version()} vs binding {SIGMA_SCAN_ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().sigma_scan_last_error().decode("utf-8", "replace")
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise RuntimeError(f"{what}: {last_error()} (sigma_status {rc})")
+
+
+def set_option(name: str, value: int) -> None:
+    check(load().sigma_scan_set_option(name.encode(), int(value)), f"sigma_scan_set_option({name})")
+
+
+def get_option(name: str) -> int:
+    return int(load().sigma_scan_get_option(name.encode()))

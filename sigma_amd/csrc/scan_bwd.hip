@@ -1,0 +1,333 @@
+// scan_bwd.hip -- selective-scan backward for gfx950 (MI355X), wave64.
+//
+// Replaces selective_scan_bwd_kernel + reverse_scan.cuh (reference:
+// models/encoders/selective_scan/csrc/selective_scan/selective_scan_bwd_kernel.cuh:66-308,
+// reverse_scan.cuh:18-401).  Mathematics: SURVEY.md App. E.2.
+//
+// Machine mapping (differs from the reference on purpose):
+//   * one wave per channel row, `nwaves` rows of one (batch, group) per workgroup;
+//   * the sequence is walked chunk by chunk (2048 = the checkpoint pitch of x) from the
+//     end; inside a chunk a cheap forward sweep (fold + wave scan only) rebuilds the state
+//     at every tile start from the chunk checkpoint, then the tiles are processed last to
+//     first: forward replay (x kept in registers) + reverse affine scan of
+//     e = a * dx ("what flows to the element on the left");
+//   * the reverse scan across lanes is a DPP row_shl scan + uniform row-head fix-up;
+//   * dB / dC are reduced over the workgroup's rows in LDS (ds_add_f32 into a swizzled
+//     [state][k][lane] tile) and leave the CU as ONE coalesced float atomic per (n, l) per
+//     workgroup -- the reference issues one global atomic per row (192 per element at
+//     stage 0); dA / dD / ddelta_bias are wave-reduced with DPP and hit memory once per row.
+#include "scan_device.h"
+#include "scan_launch.h"
+
+namespace sigma {
+
+template <typename io_t, int T>
+__global__ void __launch_bounds__(1024)
+scan_bwd_kernel(const BwdArgs q) {
+    using G = TileGeom<T>;
+    constexpr int NB = kStateBlock;
+    constexpr int TPC = 2048 / G::TILE;               // tiles per checkpoint chunk
+    constexpr int SWZ = 64 / T;                       // lane swizzle step of the dB/dC tile
+    const FwdArgs& p = q.f;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int nwaves = blockDim.x >> 6;
+    const int N = p.N, L = p.L;
+    float* sB = smem;
+    float* sC = sB + NB * G::ROW;
+    float* sdB = sC + NB * G::ROW;                    // [NB][T][64] swizzled
+    float* sdC = sdB + NB * T * 64;
+    float* sX0 = sdC + NB * T * 64;                   // [nwaves][TPC][N] state at tile start
+    float* sR = sX0 + nwaves * TPC * N;               // [nwaves][N] reverse carry a*dx of the tile to the right
+    float* sdA = sR + nwaves * N;                     // [nwaves][N]
+    float* sA = sdA + nwaves * N;                     // [nwaves][N] A[r, n]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const int lb = xcd_logical_block(blockIdx.x, gridDim.x);
+    const int b = lb / p.rowblocks;
+    const int rb = lb - b * p.rowblocks;
+    const int row0 = rb * nwaves;
+    const int r = row0 + wave;
+    const int g = row0 / p.rows_per_group;
+    const bool vec = p.vec_ok != 0;
+
+    const io_t* __restrict__ u_row = reinterpret_cast<const io_t*>(p.u) + (long)b * p.u_bs + (long)r * p.u_ds;
+    const io_t* __restrict__ d_row = reinterpret_cast<const io_t*>(p.delta) + (long)b * p.dt_bs + (long)r * p.dt_ds;
+    const io_t* __restrict__ g_row = reinterpret_cast<const io_t*>(q.dout) + (long)b * q.g_bs + (long)r * q.g_ds;
+    io_t* __restrict__ du_row = reinterpret_cast<io_t*>(q.du) + (long)b * q.du_bs + (long)r * q.du_ds;
+    io_t* __restrict__ dd_row = reinterpret_cast<io_t*>(q.ddelta) + (long)b * q.dd_bs + (long)r * q.dd_ds;
+    const io_t* __restrict__ Bg = reinterpret_cast<const io_t*>(p.B) + (long)b * p.B_bs + (long)g * p.B_gs;
+    const io_t* __restrict__ Cg = reinterpret_cast<const io_t*>(p.C) + (long)b * p.C_bs + (long)g * p.C_gs;
+    float* __restrict__ dBg = q.dB + (long)b * q.dB_bs + (long)g * q.dB_gs;
+    float* __restrict__ dCg = q.dC + (long)b * q.dC_bs + (long)g * q.dC_gs;
+    const float* __restrict__ A_row = p.A + (long)r * p.A_ds;
+    const float bias = p.bias ? p.bias[r] : 0.0f;
+    const float Dd = p.D ? p.D[r] : 0.0f;
+    const float* __restrict__ x_row = p.x ? p.x + ((long)b * p.dim + r) * (long)p.n_chunks * 2 * N : nullptr;
+
+    for (int n = lane; n < N; n += 64) {
+        sR[wave * N + n] = 0.0f; sdA[wave * N + n] = 0.0f; sA[wave * N + n] = A_row[(long)n * p.A_ns];
+    }
+    float dD_acc = 0.0f, dbias_acc = 0.0f;
+
+    const int n_chunks = (L + 2047) >> 11;
+    for (int c = n_chunks - 1; c >= 0; --c) {
+        const int cl0 = c << 11;
+        const int rem = L - cl0;
+        const int ntc = (rem >= 2048) ? TPC : (rem + G::TILE - 1) / G::TILE;
+
+        // ================= phase F: state at the start of every tile of this chunk
+        for (int n = lane; n < N; n += 64)
+            sX0[(wave * TPC + 0) * N + n] = (c > 0 && x_row) ? x_row[((long)(c - 1) * N + n) * 2 + 1] : 0.0f;
+        for (int j = 0; j + 1 < ntc; ++j) {
+            const int l0 = cl0 + j * G::TILE;
+            const int lbase = l0 + lane * T;
+            float dl[T], dlu[T];
+            {
+                float uv[T], dv[T];
+                load_items<io_t, T>(u_row, lbase, L, vec, uv);
+                load_items<io_t, T>(d_row, lbase, L, vec, dv);
+#pragma unroll
+                for (int k = 0; k < T; ++k) {
+                    float d = dv[k] + bias;
+                    if (p.softplus) { float sg; d = softplus_ref(d, sg); }
+                    d = (lbase + k < L) ? d : 0.0f;
+                    dl[k] = d;
+                    dlu[k] = d * uv[k];
+                }
+            }
+            float dsum = 0.0f;
+#pragma unroll
+            for (int k = 0; k < T; ++k) dsum += dl[k];
+            for (int nb0 = 0; nb0 < N; nb0 += NB) {
+                __syncthreads();
+                for (int idx = tid; idx < NB * (G::TILE / 4); idx += blockDim.x) {
+                    const int nn = idx / (G::TILE / 4);
+                    const int l4 = (idx - nn * (G::TILE / 4)) * 4;
+                    const int n = nb0 + nn;
+                    const int l = l0 + l4;
+                    float bv[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (n < N && l < L) load4<io_t>(Bg + (long)n * p.B_ns + l, vec, L - l, bv);
+                    *reinterpret_cast<float4*>(sB + nn * G::ROW + (l4 / T) * G::LSTR + (l4 % T)) =
+                        make_float4(bv[0], bv[1], bv[2], bv[3]);
+                }
+                __syncthreads();
+                const int nend = (N - nb0 < NB) ? (N - nb0) : NB;
+#pragma unroll 1
+                for (int nn = 0; nn < nend; ++nn) {
+                    const int n = nb0 + nn;
+                    const float A2 = sA[wave * N + n] * kLog2e;
+                    const float4* __restrict__ pB = reinterpret_cast<const float4*>(sB + nn * G::ROW + lane * G::LSTR);
+                    float xa = 0.0f;
+#pragma unroll
+                    for (int qq = 0; qq < T / 4; ++qq) {
+                        const float4 bv = pB[qq];
+                        const float bq[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) {
+                            const int k = 4 * qq + jj;
+                            xa = fmaf(fast_exp2(dl[k] * A2), xa, dlu[k] * bq[jj]);
+                        }
+                    }
+                    float pa = fast_exp2(A2 * dsum);
+                    wave_scan_inclusive(pa, xa);
+                    if (lane == 63) {
+                        const float x0 = sX0[(wave * TPC + j) * N + n];
+                        sX0[(wave * TPC + j + 1) * N + n] = fmaf(pa, x0, xa);
+                    }
+                }
+            }
+        }
+
+        // ================= phase R: tiles of this chunk, last to first
+        for (int j = ntc - 1; j >= 0; --j) {
+            const int l0 = cl0 + j * G::TILE;
+            const int lbase = l0 + lane * T;
+            float dl[T], dlu[T], uu[T], gg[T], sdxB[T], sAx[T];
+            {
+                float dv[T];
+                load_items<io_t, T>(u_row, lbase, L, vec, uu);
+                load_items<io_t, T>(d_row, lbase, L, vec, dv);
+                load_items<io_t, T>(g_row, lbase, L, vec, gg);
+#pragma unroll
+                for (int k = 0; k < T; ++k) {
+                    float d = dv[k] + bias;
+                    if (p.softplus) { float sg; d = softplus_ref(d, sg); }
+                    d = (lbase + k < L) ? d : 0.0f;
+                    dl[k] = d;
+                    dlu[k] = d * uu[k];
+                    sdxB[k] = 0.0f;
+                    sAx[k] = 0.0f;
+                }
+            }
+            float dsum = 0.0f;
+#pragma unroll
+            for (int k = 0; k < T; ++k) dsum += dl[k];
+
+            for (int nb0 = 0; nb0 < N; nb0 += NB) {
+                __syncthreads();
+                for (int idx = tid; idx < NB * (G::TILE / 4); idx += blockDim.x) {
+                    const int nn = idx / (G::TILE / 4);
+                    const int l4 = (idx - nn * (G::TILE / 4)) * 4;
+                    const int n = nb0 + nn;
+                    const int l = l0 + l4;
+                    float bv[4] = {0.f, 0.f, 0.f, 0.f}, cv[4] = {0.f, 0.f, 0.f, 0.f};
+                    if (n < N && l < L) {
+                        load4<io_t>(Bg + (long)n * p.B_ns + l, vec, L - l, bv);
+                        load4<io_t>(Cg + (long)n * p.C_ns + l, vec, L - l, cv);
+                    }
+                    const int off = nn * G::ROW + (l4 / T) * G::LSTR + (l4 % T);
+                    *reinterpret_cast<float4*>(sB + off) = make_float4(bv[0], bv[1], bv[2], bv[3]);
+                    *reinterpret_cast<float4*>(sC + off) = make_float4(cv[0], cv[1], cv[2], cv[3]);
+                    *reinterpret_cast<float4*>(sdB + idx * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+                    *reinterpret_cast<float4*>(sdC + idx * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                __syncthreads();
+
+                const int nend = (N - nb0 < NB) ? (N - nb0) : NB;
+#pragma unroll 1
+                for (int nn = 0; nn < nend; ++nn) {
+                    const int n = nb0 + nn;
+                    const float An = sA[wave * N + n];
+                    const float A2 = An * kLog2e;
+                    const float4* __restrict__ pB = reinterpret_cast<const float4*>(sB + nn * G::ROW + lane * G::LSTR);
+                    const float4* __restrict__ pC = reinterpret_cast<const float4*>(sC + nn * G::ROW + lane * G::LSTR);
+                    float a[T], bb[T], xs[T], gc[T];
+                    // ---- forward replay: x at every element
+                    float xa = 0.0f;
+#pragma unroll
+                    for (int qq = 0; qq < T / 4; ++qq) {
+                        const float4 bv = pB[qq];
+                        const float4 cv = pC[qq];
+                        const float bq[4] = {bv.x, bv.y, bv.z, bv.w};
+                        const float cq[4] = {cv.x, cv.y, cv.z, cv.w};
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) {
+                            const int k = 4 * qq + jj;
+                            a[k] = fast_exp2(dl[k] * A2);
+                            bb[k] = dlu[k] * bq[jj];
+                            gc[k] = gg[k] * cq[jj];
+                            xa = fmaf(a[k], xa, bb[k]);
+                        }
+                    }
+                    const float plane = fast_exp2(A2 * dsum);   // this lane's decay product
+                    float pa = plane;
+                    wave_scan_inclusive(pa, xa);
+                    const float pe = wave_prev_lane(pa, 1.0f);
+                    const float xe = wave_prev_lane(xa, 0.0f);
+                    float x = fmaf(pe, sX0[(wave * TPC + j) * N + n], xe);
+#pragma unroll
+                    for (int k = 0; k < T; ++k) { x = fmaf(a[k], x, bb[k]); xs[k] = x; }
+
+                    // ---- reverse: e_k = a_k * dx_k,  dx_k = g_k C_k + e_{k+1}
+                    float e = 0.0f;
+#pragma unroll
+                    for (int k = T - 1; k >= 0; --k) e = a[k] * (gc[k] + e);
+                    float pr = plane;
+                    wave_scan_inclusive_rev(pr, e);              // suffix over lanes >= this one
+                    const float pn = wave_next_lane(pr, 1.0f);
+                    const float en = wave_next_lane(e, 0.0f);
+                    e = fmaf(pn, sR[wave * N + n], en);          // e entering from the right
+                    float dAp = 0.0f;
+#pragma unroll
+                    for (int qq = T / 4 - 1; qq >= 0; --qq) {
+                        const float4 bv = pB[qq];                // B again: cheaper than T live registers
+                        const float bq[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+                        for (int jj = 3; jj >= 0; --jj) {
+                            const int k = 4 * qq + jj;
+                            const float dx = gc[k] + e;
+                            sdxB[k] = fmaf(dx, bq[jj], sdxB[k]);
+                            const float t = dx * (xs[k] - bb[k]);    // dx * a_k * x_{k-1}
+                            sAx[k] = fmaf(An, t, sAx[k]);
+                            dAp = fmaf(dl[k], t, dAp);
+                            const int so = (nn * T + k) * 64 + (lane ^ ((k * SWZ) & 63));
+                            atomicAdd(sdB + so, dx * dlu[k]);
+                            atomicAdd(sdC + so, gg[k] * xs[k]);
+                            e = a[k] * dx;
+                        }
+                    }
+                    dAp = wave_sum(dAp);
+                    if (lane == 0) {
+                        sR[wave * N + n] = e;                    // a*dx of the tile's first element
+                        sdA[wave * N + n] += dAp;
+                    }
+                }
+                __syncthreads();
+                // ---- flush the workgroup-reduced dB/dC block: one coalesced atomic per (n, l)
+                for (int idx = tid; idx < NB * G::TILE; idx += blockDim.x) {
+                    const int nn = idx / G::TILE;
+                    const int li = idx - nn * G::TILE;
+                    const int n = nb0 + nn;
+                    const int l = l0 + li;
+                    if (n < N && l < L) {
+                        const int ln = li / T, k = li % T;
+                        const int so = (nn * T + k) * 64 + (ln ^ ((k * SWZ) & 63));
+                        atomicAdd(dBg + (long)n * q.dB_ns + l, sdB[so]);
+                        atomicAdd(dCg + (long)n * q.dC_ns + l, sdC[so]);
+                    }
+                }
+            }
+            // ---- per-element results
+            float duv[T], ddv[T], dv2[T];
+            // softplus' = sigmoid(raw): re-read delta (L2-resident) instead of holding T registers
+            // across the whole state loop
+            load_items<io_t, T>(d_row, lbase, L, vec, dv2);
+#pragma unroll
+            for (int k = 0; k < T; ++k) {
+                duv[k] = fmaf(Dd, gg[k], dl[k] * sdxB[k]);
+                float dd = fmaf(uu[k], sdxB[k], sAx[k]);
+                if (p.softplus) { float sg; (void)softplus_ref(dv2[k] + bias, sg); dd *= sg; }
+                ddv[k] = dd;
+                if (lbase + k < L) { dD_acc = fmaf(gg[k], uu[k], dD_acc); dbias_acc += dd; }
+            }
+            store_items<io_t, T>(du_row, lbase, L, vec, duv);
+            store_items<io_t, T>(dd_row, lbase, L, vec, ddv);
+        }
+    }
+
+    dD_acc = wave_sum(dD_acc);
+    dbias_acc = wave_sum(dbias_acc);
+    if (lane == 0) {
+        if (q.dD) atomicAdd(q.dD + r, dD_acc);
+        if (q.dbias) atomicAdd(q.dbias + r, dbias_acc);
+    }
+    for (int n = lane; n < N; n += 64)
+        atomicAdd(q.dA + (long)r * q.dA_ds + (long)n * q.dA_ns, sdA[wave * N + n]);
+}
+
+template <typename io_t, int T>
+static hipError_t launch_bwd_t(const BwdArgs& a, int nwaves, hipStream_t stream) {
+    const size_t lds = bwd_lds_bytes(T, nwaves, a.f.N);
+    const int grid = a.f.rowblocks * a.f.batch;
+    auto kern = scan_bwd_kernel<io_t, T>;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(nwaves * 64), lds, stream, a);
+    return hipGetLastError();
+}
+
+template <typename io_t>
+static hipError_t launch_bwd_io(const BwdArgs& a, int T, int nwaves, hipStream_t stream) {
+    switch (T) {
+        case 4: return launch_bwd_t<io_t, 4>(a, nwaves, stream);
+        case 8: return launch_bwd_t<io_t, 8>(a, nwaves, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+hipError_t launch_scan_bwd(const BwdArgs& a, int dtype, int T, int nwaves, hipStream_t stream) {
+    switch (dtype) {
+        case 0: return launch_bwd_io<float>(a, T, nwaves, stream);
+        case 1: return launch_bwd_io<f16_t>(a, T, nwaves, stream);
+        case 2: return launch_bwd_io<bf16_t>(a, T, nwaves, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+}  // namespace sigma

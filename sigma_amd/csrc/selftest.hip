@@ -1,0 +1,59 @@
+// selftest.hip -- on-device check of the wave64 DPP scan primitives in scan_device.h
+// against serial loops over LDS.  One wave, a few hundred instructions.
+#include "scan_device.h"
+#include "scan_launch.h"
+
+namespace sigma {
+
+__global__ void __launch_bounds__(64) selftest_kernel(float* out) {
+    __shared__ float sp[64], sx[64];
+    const int lane = threadIdx.x;
+    // deterministic, lane-asymmetric data: p in (0.5, 1], x in [-1, 1]
+    const float p0 = 0.5f + 0.5f * (float)((lane * 37 + 11) % 64) / 64.0f;
+    const float x0 = (float)((lane * 53 + 7) % 64) / 32.0f - 1.0f;
+    sp[lane] = p0; sx[lane] = x0;
+    __syncthreads();
+
+    // forward inclusive
+    float p = p0, x = x0;
+    wave_scan_inclusive(p, x);
+    float rp = 1.0f, rx = 0.0f;
+    for (int i = 0; i <= lane; ++i) { rx = fmaf(sp[i], rx, sx[i]); rp *= sp[i]; }
+    const float e_fwd = fmaxf(fabsf(p - rp) / fabsf(rp), fabsf(x - rx));
+
+    // reverse inclusive (suffix)
+    float q = p0, y = x0;
+    wave_scan_inclusive_rev(q, y);
+    float sq = 1.0f, sy = 0.0f;
+    for (int i = 63; i >= lane; --i) { sy = fmaf(sp[i], sy, sx[i]); sq *= sp[i]; }
+    const float e_rev = fmaxf(fabsf(q - sq) / fabsf(sq), fabsf(y - sy));
+
+    const float pv = wave_prev_lane(x0, -7.0f);
+    const float e_prev = fabsf(pv - (lane == 0 ? -7.0f : sx[lane - 1]));
+    const float nx = wave_next_lane(x0, 9.0f);
+    const float e_next = fabsf(nx - (lane == 63 ? 9.0f : sx[lane + 1]));
+
+    const float s = wave_sum(x0);
+    float ss = 0.0f;
+    for (int i = 0; i < 64; ++i) ss += sx[i];
+    const float e_sum = fabsf(s - ss);
+
+    // max over lanes through LDS
+    __shared__ float red[5][64];
+    red[0][lane] = e_fwd; red[1][lane] = e_rev; red[2][lane] = e_prev; red[3][lane] = e_next; red[4][lane] = e_sum;
+    __syncthreads();
+    if (lane == 0) {
+        float m[5] = {0, 0, 0, 0, 0};
+        for (int k = 0; k < 5; ++k) for (int i = 0; i < 64; ++i) m[k] = fmaxf(m[k], red[k][i]);
+        const bool bad = m[0] > 1e-5f || m[1] > 1e-5f || m[2] != 0.0f || m[3] != 0.0f || m[4] > 1e-4f;
+        out[0] = bad ? 1.0f : 0.0f;
+        for (int k = 0; k < 5; ++k) out[1 + k] = m[k];
+    }
+}
+
+hipError_t launch_selftest(float* out, hipStream_t stream) {
+    hipLaunchKernelGGL(selftest_kernel, dim3(1), dim3(64), 0, stream, out);
+    return hipGetLastError();
+}
+
+}  // namespace sigma

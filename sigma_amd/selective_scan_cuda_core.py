@@ -1,0 +1,151 @@
+"""Drop-in for the reference's compiled extension module ``selective_scan_cuda_core``.
+
+Reference: models/encoders/selective_scan/csrc/selective_scan/selective_scan.cpp
+(``fwd`` :165-249, ``bwd`` :251-362, pybind :364-367).  Same positional signatures, same
+checks (RuntimeError where the reference TORCH_CHECKs), same outputs:
+
+    fwd(u, delta, A, B, C, D_, delta_bias_, delta_softplus, nrows) -> [out, x]
+    bwd(u, delta, A, B, C, D_, delta_bias_, dout, x_, delta_softplus, nrows)
+        -> [du, ddelta, dA, dB, dC, dD, ddelta_bias]
+
+The work is done by the hand-written HIP kernels in libsigma_hip.so through the C ABI
+of include/sigma_scan.h; this file only validates, allocates outputs exactly like the
+reference host code, and forwards raw device pointers + the current HIP stream.
+There is no fallback: without the library (or a GPU tensor) these functions raise.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional
+
+import torch
+
+from . import _capi
+
+_DTYPES = {torch.float32: _capi.DTYPE_F32, torch.float16: _capi.DTYPE_F16, torch.bfloat16: _capi.DTYPE_BF16}
+
+
+def _check(cond: bool, msg: str) -> None:
+    if not cond:
+        raise RuntimeError(msg)
+
+
+def _check_common(u, delta, A, B, C, D_, delta_bias_, nrows):
+    _check(u.dtype in _DTYPES, "selective_scan: input type must be float32, float16 or bfloat16")
+    _check(A.dtype == torch.float32, "selective_scan: A must be float32")
+    _check(delta.dtype == u.dtype and B.dtype == u.dtype and C.dtype == u.dtype,
+           "selective_scan: u, delta, B, C must share one dtype")
+    for name, t in (("u", u), ("delta", delta), ("A", A), ("B", B), ("C", C)):
+        _check(t.is_cuda, f"selective_scan: {name} must be a GPU tensor")
+    _check(u.dim() == 3, "u must have shape (batch_size, dim, seqlen)")
+    _check(u.stride(-1) == 1 or u.size(-1) <= 1, "u.stride(-1) must be 1")
+    _check(delta.stride(-1) == 1 or delta.size(-1) <= 1, "delta.stride(-1) must be 1")
+    batch, dim, seqlen = u.shape
+    _check(A.dim() == 2, "A must have shape (dim, dstate)")
+    dstate = A.size(1)
+    _check(B.dim() == 4, "B must have shape (batch_size, n_groups, dstate, seqlen)")
+    n_groups = B.size(1)
+    nrows = int(nrows)
+    _check(nrows >= 1 and dim % (n_groups * nrows) == 0, "dims should be dividable by n_groups * nrows")
+    _check(dstate <= _capi.SIGMA_SCAN_MAX_DSTATE // nrows,
+           "selective_scan only supports state dimension <= 256 / nrows")
+    _check(tuple(delta.shape) == (batch, dim, seqlen), "delta must have shape (batch_size, dim, seqlen)")
+    _check(tuple(A.shape) == (dim, dstate), "A must have shape (dim, dstate)")
+    _check(tuple(B.shape) == (batch, n_groups, dstate, seqlen),
+           "B must have shape (batch_size, n_groups, dstate, seqlen)")
+    _check(B.stride(-1) == 1 or seqlen <= 1, "B.stride(-1) must be 1")
+    _check(tuple(C.shape) == (batch, n_groups, dstate, seqlen),
+           "C must have shape (batch_size, n_groups, dstate, seqlen)")
+    _check(C.stride(-1) == 1 or seqlen <= 1, "C.stride(-1) must be 1")
+    for name, t in (("D", D_), ("delta_bias", delta_bias_)):
+        if t is not None:
+            _check(t.dtype == torch.float32, f"{name} must be float32")
+            _check(t.is_cuda, f"{name} must be a GPU tensor")
+            _check(tuple(t.shape) == (dim,), f"{name} must have shape (dim)")
+            _check(t.stride(-1) == 1 or dim <= 1, f"{name}.stride(-1) must be 1")
+    return batch, dim, seqlen, dstate, n_groups
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _fill_fwd(fp: _capi.FwdParams, u, delta, A, B, C, D_, delta_bias_, out, x, delta_softplus, sizes):
+    batch, dim, seqlen, dstate, n_groups = sizes
+    fp.batch, fp.dim, fp.seqlen, fp.dstate, fp.n_groups = batch, dim, seqlen, dstate, n_groups
+    fp.n_chunks = (seqlen + _capi.SIGMA_SCAN_CHUNK - 1) // _capi.SIGMA_SCAN_CHUNK
+    fp.io_dtype = _DTYPES[u.dtype]
+    fp.delta_softplus = 1 if delta_softplus else 0
+    fp.u, fp.delta, fp.A, fp.B, fp.C = _ptr(u), _ptr(delta), _ptr(A), _ptr(B), _ptr(C)
+    fp.D, fp.delta_bias = _ptr(D_), _ptr(delta_bias_)
+    fp.out, fp.x = _ptr(out), _ptr(x)
+    fp.u_batch_stride, fp.u_d_stride = u.stride(0), u.stride(1)
+    fp.delta_batch_stride, fp.delta_d_stride = delta.stride(0), delta.stride(1)
+    fp.A_d_stride, fp.A_dstate_stride = A.stride(0), A.stride(1)
+    fp.B_batch_stride, fp.B_group_stride, fp.B_dstate_stride = B.stride(0), B.stride(1), B.stride(2)
+    fp.C_batch_stride, fp.C_group_stride, fp.C_dstate_stride = C.stride(0), C.stride(1), C.stride(2)
+    if out is not None:
+        fp.out_batch_stride, fp.out_d_stride = out.stride(0), out.stride(1)
+
+
+def fwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B: torch.Tensor, C: torch.Tensor,
+        D_: Optional[torch.Tensor], delta_bias_: Optional[torch.Tensor], delta_softplus: bool,
+        nrows: int) -> List[torch.Tensor]:
+    """Selective scan forward (selective_scan.cpp:165-249).  ``nrows`` only takes part in
+    the shape checks: the row-to-workgroup mapping is chosen by the library."""
+    lib = _capi.load()
+    sizes = _check_common(u, delta, A, B, C, D_, delta_bias_, nrows)
+    batch, dim, seqlen, dstate, _ = sizes
+    n_chunks = (seqlen + _capi.SIGMA_SCAN_CHUNK - 1) // _capi.SIGMA_SCAN_CHUNK
+    out = torch.empty_like(delta)                                   # selective_scan.cpp:226
+    x = torch.empty((batch, dim, n_chunks, dstate * 2), device=u.device, dtype=torch.float32)  # :228
+    if batch == 0 or seqlen == 0:
+        return [out, x]
+    fp = _capi.FwdParams()
+    _fill_fwd(fp, u, delta, A, B, C, D_, delta_bias_, out, x, delta_softplus, sizes)
+    with torch.cuda.device(u.device):                               # CUDAGuard, :240
+        stream = torch.cuda.current_stream(u.device).cuda_stream    # :241
+        _capi.check(lib.sigma_selective_scan_fwd(ctypes.byref(fp), ctypes.c_void_p(stream)), "selective_scan_fwd")
+    return [out, x]
+
+
+def bwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B: torch.Tensor, C: torch.Tensor,
+        D_: Optional[torch.Tensor], delta_bias_: Optional[torch.Tensor], dout: torch.Tensor,
+        x_: Optional[torch.Tensor], delta_softplus: bool, nrows: int) -> List[Optional[torch.Tensor]]:
+    """Selective scan backward (selective_scan.cpp:251-362)."""
+    lib = _capi.load()
+    sizes = _check_common(u, delta, A, B, C, D_, delta_bias_, nrows)
+    batch, dim, seqlen, dstate, n_groups = sizes
+    _check(dout.dtype == u.dtype, "dout must have the dtype of u")
+    _check(dout.is_cuda, "dout must be a GPU tensor")
+    _check(tuple(dout.shape) == (batch, dim, seqlen), "dout must have shape (batch_size, dim, seqlen)")
+    _check(dout.stride(-1) == 1 or seqlen <= 1, "dout.stride(-1) must be 1")
+    n_chunks = (seqlen + _capi.SIGMA_SCAN_CHUNK - 1) // _capi.SIGMA_SCAN_CHUNK
+    if n_chunks > 1:
+        _check(x_ is not None, "x is required when seqlen > 2048")   # :320
+    if x_ is not None:
+        _check(x_.dtype == torch.float32 and x_.is_cuda and x_.is_contiguous(), "x must be a contiguous float32 GPU tensor")
+        _check(tuple(x_.shape) == (batch, dim, n_chunks, 2 * dstate),
+               "x must have shape (batch_size, dim, n_chunks, 2 * dstate)")
+    du = torch.empty_like(u)                                         # :329-337
+    ddelta = torch.empty_like(delta)
+    dA = torch.zeros_like(A)
+    dB = torch.zeros_like(B, dtype=torch.float32)
+    dC = torch.zeros_like(C, dtype=torch.float32)
+    dD = torch.zeros_like(D_) if D_ is not None else None
+    ddelta_bias = torch.zeros_like(delta_bias_) if delta_bias_ is not None else None
+    if batch > 0 and seqlen > 0:
+        bp = _capi.BwdParams()
+        _fill_fwd(bp.fwd, u, delta, A, B, C, D_, delta_bias_, None, x_, delta_softplus, sizes)
+        bp.dout, bp.du, bp.ddelta = _ptr(dout), _ptr(du), _ptr(ddelta)
+        bp.dA, bp.dB, bp.dC, bp.dD, bp.ddelta_bias = _ptr(dA), _ptr(dB), _ptr(dC), _ptr(dD), _ptr(ddelta_bias)
+        bp.dout_batch_stride, bp.dout_d_stride = dout.stride(0), dout.stride(1)
+        bp.du_batch_stride, bp.du_d_stride = du.stride(0), du.stride(1)
+        bp.ddelta_batch_stride, bp.ddelta_d_stride = ddelta.stride(0), ddelta.stride(1)
+        bp.dA_d_stride, bp.dA_dstate_stride = dA.stride(0), dA.stride(1)
+        bp.dB_batch_stride, bp.dB_group_stride, bp.dB_dstate_stride = dB.stride(0), dB.stride(1), dB.stride(2)
+        bp.dC_batch_stride, bp.dC_group_stride, bp.dC_dstate_stride = dC.stride(0), dC.stride(1), dC.stride(2)
+        with torch.cuda.device(u.device):
+            stream = torch.cuda.current_stream(u.device).cuda_stream
+            _capi.check(lib.sigma_selective_scan_bwd(ctypes.byref(bp), ctypes.c_void_p(stream)), "selective_scan_bwd")
+    return [du, ddelta, dA, dB.to(B.dtype), dC.to(C.dtype), dD, ddelta_bias]   # :360

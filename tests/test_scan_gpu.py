@@ -1,0 +1,309 @@
+"""GPU parity tests of the HIP selective-scan operator (run with -m gpu on an MI355X).
+
+Every call goes python -> ctypes -> C ABI (include/sigma_scan.h) -> HIP kernel.  The
+checker is the CPU oracle (oracle/scan_oracle.c) and the committed golden vectors that
+were produced by the reference's own selective_scan_ref + autograd.
+
+Tolerances are the reference's (models/encoders/selective_scan/test_selective_scan.py:148-151,
+216-224): fwd fp32 rtol 6e-4 / atol 2e-3, fp16 3e-3 / 5e-3, bf16 3e-2 / 5e-2,
+weights 1e-3 / 1e-3, with the same 2x / 5x-10x multipliers on the gradients.
+"""
+import ast
+import glob
+import itertools
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+FILES = sorted(glob.glob(os.path.join(GOLDEN, "scan_*.npz")))
+
+
+def _tols(dtype):
+    if dtype == torch.float32:
+        return 6e-4, 2e-3
+    if dtype == torch.float16:
+        return 3e-3, 5e-3
+    return 3e-2, 5e-2
+
+
+def _core():
+    from sigma_amd import selective_scan_cuda_core as core
+    return core
+
+
+def _fn():
+    from sigma_amd.selective_scan import selective_scan_fn
+    return selective_scan_fn
+
+
+def _oracle():
+    from oracle import scan_oracle as so
+    return so
+
+
+def test_native_library_and_wave_primitives():
+    from sigma_amd import _capi
+    lib = _capi.load()
+    assert torch.cuda.is_available()
+    rc = lib.sigma_scan_selftest(None)
+    assert rc == 0, _capi.last_error()
+
+
+def _load_golden(path):
+    z = np.load(path, allow_pickle=False)
+    meta = ast.literal_eval(str(z["meta"]))
+    dt = getattr(torch, meta["dtype"])
+    t = {}
+    for k in z.files:
+        if k == "meta":
+            continue
+        v = torch.from_numpy(z[k])
+        if k in ("in_u", "in_delta", "in_B", "in_C", "in_dout", "out"):
+            v = v.to(dt)
+        t[k] = v
+    return meta, t
+
+
+@pytest.mark.parametrize("path", FILES, ids=[os.path.basename(p)[5:-4] for p in FILES])
+def test_against_reference_golden_vectors(path):
+    """HIP fwd + all seven grads vs outputs of the REFERENCE's own CPU code."""
+    meta, t = _load_golden(path)
+    dt = getattr(torch, meta["dtype"])
+    rtol, atol = _tols(dt)
+    dev = "cuda"
+    leaves = {}
+    for k in ("u", "delta", "A", "B", "C", "D", "delta_bias"):
+        v = t.get("in_" + k)
+        leaves[k] = None if v is None else v.to(dev).requires_grad_()
+    out = _fn()(leaves["u"], leaves["delta"], leaves["A"], leaves["B"], leaves["C"], leaves["D"],
+                leaves["delta_bias"], meta["softplus"], 1)
+    assert out.dtype == dt
+    torch.testing.assert_close(out.float().cpu(), t["out"].float(), rtol=rtol, atol=atol)
+    out.backward(t["in_dout"].to(dev))
+    mult = {"u": (2, 2), "delta": (5, 10), "B": (1, 1), "C": (1, 1)}
+    for k in ("u", "delta", "B", "C"):
+        rm, am = mult[k]
+        torch.testing.assert_close(leaves[k].grad.float().cpu(), t["grad_" + k].float(), rtol=rtol * rm,
+                                   atol=atol * am, msg=lambda m, k=k: f"d{k}: {m}")
+    torch.testing.assert_close(leaves["A"].grad.cpu(), t["grad_A"], rtol=1e-3, atol=5e-3)
+    if leaves["D"] is not None:
+        torch.testing.assert_close(leaves["D"].grad.cpu(), t["grad_D"], rtol=1e-3, atol=1e-3)
+    if leaves["delta_bias"] is not None:
+        torch.testing.assert_close(leaves["delta_bias"].grad.cpu(), t["grad_delta_bias"], rtol=1e-3, atol=1e-3)
+
+
+def _ref_test_inputs(seqlen, itype, groups, has_D, has_bias, batch=2, dim=24, dstate=8, seed=0):
+    """Input distributions of the reference unit test (test_selective_scan.py:153-179)."""
+    g = torch.Generator().manual_seed(seed)
+    A = -0.5 * torch.rand(dim, dstate, generator=g)
+    shp = (batch, dstate, seqlen) if groups == 0 else (batch, groups, dstate, seqlen)
+    B = torch.randn(*shp, generator=g).to(itype)
+    C = torch.randn(*shp, generator=g).to(itype)
+    D = torch.randn(dim, generator=g) if has_D else None
+    bias = 0.5 * torch.rand(dim, generator=g) if has_bias else None
+    u = torch.randn(batch, dim, seqlen, generator=g).to(itype)
+    delta = (0.5 * torch.rand(batch, dim, seqlen, generator=g)).to(itype)
+    dout = torch.randn(batch, dim, seqlen, generator=g).to(itype)
+    return u, delta, A, B, C, D, bias, dout
+
+
+def _run_hip(u, delta, A, B, C, D, bias, dout, softplus, nrows):
+    dev = "cuda"
+    L = {k: (None if v is None else v.to(dev).requires_grad_()) for k, v in
+         dict(u=u, delta=delta, A=A, B=B, C=C, D=D, bias=bias).items()}
+    out = _fn()(L["u"], L["delta"], L["A"], L["B"], L["C"], L["D"], L["bias"], softplus, nrows)
+    out.backward(dout.to(dev))
+    grads = [None if L[k] is None else L[k].grad for k in ("u", "delta", "A", "B", "C", "D", "bias")]
+    return out, grads
+
+
+def _compare(out, grads, u, delta, A, B, C, D, bias, dout, softplus, itype):
+    so = _oracle()
+    rtol, atol = _tols(itype)
+    ref = so.selective_scan_oracle(u, delta, A, B, C, D, bias, softplus, acc64=True)
+    torch.testing.assert_close(out.float().cpu(), ref.float(), rtol=rtol, atol=atol, msg=lambda m: f"out: {m}")
+    rg = so.selective_scan_oracle_bwd(u, delta, A, B, C, D, bias, dout, softplus)
+    names = ["u", "delta", "A", "B", "C", "D", "delta_bias"]
+    tol = {"u": (rtol * 2, atol * 2), "delta": (rtol * 5, atol * 10), "A": (1e-3, 5e-3), "B": (rtol, atol),
+           "C": (rtol, atol), "D": (1e-3, 1e-3), "delta_bias": (1e-3, 1e-3)}
+    for name, g, r in zip(names, grads, rg):
+        if r is None:
+            assert g is None
+            continue
+        rr = r.to(itype).float() if name in ("u", "delta", "B", "C") else r
+        rt, at = tol[name]
+        # long fp32 reductions scale their absolute error with the magnitude of the result
+        at = max(at, 2e-4 * float(rr.abs().max())) if name in ("A", "D", "delta_bias") else at
+        torch.testing.assert_close(g.float().cpu(), rr, rtol=rt, atol=at, msg=lambda m, name=name: f"d{name}: {m}")
+
+
+GRID = list(itertools.product(
+    [64, 128, 256, 372, 512, 784, 1024, 1134, 2048, 4096],       # seqlen (test_selective_scan.py:139)
+    [torch.float32, torch.float16, torch.bfloat16],
+    [(False, False, False), (True, True, True), (True, False, True), (False, True, False)],  # bias, softplus, D
+    [0, 2],                                                        # varBC groups (0 => 3-D B/C)
+    [1, 4],                                                        # nrows
+))
+
+
+@pytest.mark.parametrize("seqlen,itype,flags,groups,nrows", GRID,
+                         ids=[f"L{g[0]}-{str(g[1]).split('.')[-1]}-b{int(g[2][0])}s{int(g[2][1])}d{int(g[2][2])}-g{g[3]}-r{g[4]}"
+                              for g in GRID])
+def test_reference_unit_test_grid(seqlen, itype, flags, groups, nrows):
+    """The reference's own parametrisation (batch 2, dim 24, dstate 8), fwd + 7 grads."""
+    has_bias, softplus, has_D = flags
+    inp = _ref_test_inputs(seqlen, itype, groups, has_D, has_bias)
+    u, delta, A, B, C, D, bias, dout = inp
+    out, grads = _run_hip(u, delta, A, B, C, D, bias, dout, softplus, nrows)
+    _compare(out, grads, u, delta, A, B, C, D, bias, dout, softplus, itype)
+
+
+def _model_like(batch, KD, L, N, G, seed=0, itype=torch.float32):
+    """Magnitudes of a freshly initialised SS2D block (vmamba.py:729-782): A = -(1..N),
+    dt bias = softplus^-1(U_log[1e-3, 1e-1]), D = 1, small dt projections."""
+    g = torch.Generator().manual_seed(seed)
+    A = -torch.arange(1, N + 1, dtype=torch.float32).repeat(KD, 1) * (1 + 0.05 * torch.rand(KD, N, generator=g))
+    B = torch.randn(batch, G, N, L, generator=g).to(itype)
+    C = torch.randn(batch, G, N, L, generator=g).to(itype)
+    D = 1.0 + 0.1 * torch.randn(KD, generator=g)
+    tgt = torch.exp(torch.rand(KD, generator=g) * (np.log(0.1) - np.log(0.001)) + np.log(0.001))
+    bias = tgt + torch.log(-torch.expm1(-tgt))
+    u = torch.randn(batch, KD, L, generator=g).to(itype)
+    delta = (0.5 * torch.randn(batch, KD, L, generator=g)).to(itype)
+    dout = torch.randn(batch, KD, L, generator=g).to(itype)
+    return u, delta, A, B, C, D, bias, dout
+
+
+STAGE_SHAPES = [
+    # (batch, KD, L, N, G)  -- SURVEY.md Appendix A, sigma_tiny/small @480x640
+    (1, 768, 19200, 16, 4),     # encoder stage 0 (the headline kernel shape)
+    (1, 1536, 4800, 16, 4),     # encoder stage 1
+    (2, 3072, 1200, 16, 4),     # encoder stage 2, batch 2
+    (1, 6144, 300, 16, 4),      # encoder stage 3
+    (1, 192, 19200, 4, 1),      # CroMB stage 0
+    (1, 384, 38400, 4, 2),      # ConMB stage 0 (longest sequence at 480x640)
+    (1, 768, 19200, 4, 4),      # decoder @120x160
+]
+
+
+@pytest.mark.parametrize("shape", STAGE_SHAPES, ids=["x".join(map(str, s)) for s in STAGE_SHAPES])
+def test_real_stage_shapes_forward_and_backward(shape):
+    batch, KD, L, N, G = shape
+    u, delta, A, B, C, D, bias, dout = _model_like(batch, KD, L, N, G)
+    out, grads = _run_hip(u, delta, A, B, C, D, bias, dout, True, 4 if (KD // G) % 4 == 0 else 1)
+    _compare(out, grads, u, delta, A, B, C, D, bias, dout, True, torch.float32)
+
+
+def test_checkpoint_tensor_matches_reference_layout():
+    """x[b, r, c, :] = float2[n] (prod a over l <= end(c), state at end(c))
+    (selective_scan.cpp:225-228; selective_scan_fwd_kernel.cuh:181-184)."""
+    so = _oracle()
+    batch, KD, L, N, G = 2, 8, 5000, 4, 2
+    u, delta, A, B, C, D, bias, _ = _model_like(batch, KD, L, N, G, seed=3)
+    dev = "cuda"
+    out, x = _core().fwd(u.to(dev), delta.to(dev), A.to(dev), B.to(dev), C.to(dev), D.to(dev), bias.to(dev), True, 1)
+    assert x.shape == (batch, KD, 3, 2 * N) and x.dtype == torch.float32
+    x = x.cpu().view(batch, KD, 3, N, 2)
+    dl = torch.nn.functional.softplus(delta.double() + bias.double()[None, :, None])
+    for c, end in enumerate([2048, 4096, 5000]):
+        _, st = so.selective_scan_oracle(u[..., :end], delta[..., :end], A, B[..., :end], C[..., :end], D, bias, True,
+                                         acc64=True, return_last_state=True)
+        torch.testing.assert_close(x[:, :, c, :, 1], st, rtol=1e-3, atol=1e-4)
+        prod = torch.exp(dl[..., :end].sum(-1)[..., None] * A.double()[None])
+        torch.testing.assert_close(x[:, :, c, :, 0].double(), prod, rtol=1e-3, atol=1e-30)
+
+
+def test_strided_and_unaligned_inputs():
+    """Arbitrary batch/row strides are honoured (selective_scan.cpp:88-103); odd L and
+    offset storage take the scalar path."""
+    so = _oracle()
+    dev = "cuda"
+    batch, KD, L, N, G = 2, 12, 777, 4, 3
+    u, delta, A, B, C, D, bias, dout = _model_like(batch, KD, L, N, G, seed=5)
+    big_u = torch.zeros(batch, KD, 2, L + 3, device=dev)
+    big_u[:, :, 1, 1:L + 1] = u.to(dev)
+    u_s = big_u[:, :, 1, 1:L + 1]                       # strided in batch/row, storage offset 1 element
+    big_d = torch.zeros(KD, batch, L, device=dev)
+    big_d.copy_(delta.to(dev).transpose(0, 1))
+    d_s = big_d.transpose(0, 1)                          # (batch, KD, L) with swapped strides
+    assert u_s.stride(-1) == 1 and d_s.stride(-1) == 1 and not d_s.is_contiguous()
+    out, x = _core().fwd(u_s, d_s, A.to(dev), B.to(dev), C.to(dev), D.to(dev), bias.to(dev), True, 1)
+    ref = so.selective_scan_oracle(u, delta, A, B, C, D, bias, True, acc64=True)
+    torch.testing.assert_close(out.cpu(), ref, rtol=6e-4, atol=2e-3)
+    grads = _core().bwd(u_s, d_s, A.to(dev), B.to(dev), C.to(dev), D.to(dev), bias.to(dev), dout.to(dev), x, True, 1)
+    rg = so.selective_scan_oracle_bwd(u, delta, A, B, C, D, bias, dout, True)
+    for name, g, r in zip(["u", "delta", "A", "B", "C", "D", "bias"], grads, rg):
+        torch.testing.assert_close(g.cpu(), r, rtol=3e-3, atol=2e-3 + 2e-4 * float(r.abs().max()),
+                                   msg=lambda m, name=name: f"d{name}: {m}")
+
+
+@pytest.mark.parametrize("opt", [("fwd_items", 4), ("fwd_items", 8), ("fwd_items", 16), ("fwd_waves", 1),
+                                 ("fwd_waves", 2), ("fwd_waves", 16), ("bwd_items", 4), ("bwd_items", 8),
+                                 ("bwd_waves", 1), ("bwd_waves", 8)])
+def test_every_launch_geometry_is_correct(opt):
+    """All (items per lane, rows per workgroup) variants compute the same thing."""
+    from sigma_amd import _capi
+    name, val = opt
+    batch, KD, L, N, G = 2, 64, 2500, 16, 2
+    u, delta, A, B, C, D, bias, dout = _model_like(batch, KD, L, N, G, seed=7)
+    _capi.set_option(name, val)
+    try:
+        out, grads = _run_hip(u, delta, A, B, C, D, bias, dout, True, 1)
+    finally:
+        _capi.set_option(name, 0)
+    _compare(out, grads, u, delta, A, B, C, D, bias, dout, True, torch.float32)
+
+
+def test_error_behaviour_matches_reference_checks():
+    core = _core()
+    dev = "cuda"
+    u = torch.randn(1, 8, 16, device=dev)
+    A = -torch.rand(8, 4, device=dev)
+    Bm = torch.randn(1, 1, 4, 16, device=dev)
+    with pytest.raises(RuntimeError):                       # dtype mismatch (selective_scan.cpp:179-181)
+        core.fwd(u, u.half(), A, Bm, Bm, None, None, False, 1)
+    with pytest.raises(RuntimeError):                       # dim % (groups*nrows) (selective_scan.cpp:200)
+        core.fwd(u, u, A, torch.randn(1, 3, 4, 16, device=dev), torch.randn(1, 3, 4, 16, device=dev), None, None, False, 1)
+    with pytest.raises(RuntimeError):                       # CPU tensor (selective_scan.cpp:183-187)
+        core.fwd(u.cpu(), u.cpu(), A.cpu(), Bm.cpu(), Bm.cpu(), None, None, False, 1)
+    with pytest.raises(RuntimeError):                       # A must be fp32 (:177)
+        core.fwd(u, u, A.half(), Bm, Bm, None, None, False, 1)
+    long_u = torch.randn(1, 8, 3000, device=dev)
+    long_B = torch.randn(1, 1, 4, 3000, device=dev)
+    with pytest.raises(RuntimeError):                       # x required when n_chunks > 1 (:320)
+        core.bwd(long_u, long_u, A, long_B, long_B, None, None, long_u, None, False, 1)
+
+
+def test_empty_and_tiny_sequences():
+    core = _core()
+    so = _oracle()
+    dev = "cuda"
+    A = -torch.rand(4, 3)
+    out, x = core.fwd(torch.randn(1, 4, 0, device=dev), torch.randn(1, 4, 0, device=dev), A.to(dev),
+                      torch.randn(1, 1, 3, 0, device=dev), torch.randn(1, 1, 3, 0, device=dev), None, None, False, 1)
+    assert out.shape == (1, 4, 0)
+    for L in (1, 2, 3, 5, 63, 65):
+        u, d = torch.randn(2, 4, L), torch.rand(2, 4, L)
+        Bm, Cm = torch.randn(2, 2, 3, L), torch.randn(2, 2, 3, L)
+        out, _ = core.fwd(u.to(dev), d.to(dev), A.to(dev), Bm.to(dev), Cm.to(dev), None, None, False, 1)
+        torch.testing.assert_close(out.cpu(), so.selective_scan_oracle(u, d, A, Bm, Cm, acc64=True), rtol=6e-4, atol=2e-3)
+
+
+def test_full_size_properties_linearity_and_determinism():
+    """Size-independent properties at the headline shape (1, 768, 19200), N=16: the scan is
+    linear in u for fixed delta, and the forward is bit-deterministic (no atomics)."""
+    dev = "cuda"
+    batch, KD, L, N, G = 1, 768, 19200, 16, 4
+    u, delta, A, B, C, D, bias, _ = [None if t is None else t.to(dev) for t in _model_like(batch, KD, L, N, G, seed=11)]
+    u2 = torch.randn_like(u)
+    f = lambda uu: _core().fwd(uu, delta, A, B, C, None, bias, True, 4)[0]
+    lhs = f(u + 2 * u2)
+    rhs = f(u) + 2 * f(u2)
+    torch.testing.assert_close(lhs, rhs, rtol=2e-4, atol=2e-4)
+    # determinism of the forward (no atomics on the forward path)
+    assert torch.equal(f(u), f(u))
