@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SIGMA_SCAN_ABI_VERSION 1
+#define SIGMA_SCAN_ABI_VERSION 2
 
 /* dtype of u, delta, B, C, out, dout, du, ddelta  (input_t of the reference,
  * selective_scan.cpp:174: float / half / bfloat16).  A, D, delta_bias, x, dA,
@@ -99,10 +99,17 @@ typedef struct sigma_scan_bwd_params {
     void *du;                    /* (B, dim, L)   io_dtype, fully written */
     void *ddelta;                /* (B, dim, L)   io_dtype, fully written */
     float *dA;                   /* (dim, N)      f32, ACCUMULATED into (caller zeroes, :331) */
-    float *dB;                   /* (B, G, N, L)  f32, ACCUMULATED into (caller zeroes, :332) */
-    float *dC;                   /* (B, G, N, L)  f32, ACCUMULATED into (caller zeroes, :333) */
+    float *dB;                   /* (B, G, N, L)  f32, fully WRITTEN (the reference zero-fills and
+                                    atomically accumulates, :332; here a deterministic 2-stage sum) */
+    float *dC;                   /* (B, G, N, L)  f32, fully WRITTEN */
     float *dD;                   /* (dim) or NULL f32, ACCUMULATED into */
     float *ddelta_bias;          /* (dim) or NULL f32, ACCUMULATED into */
+    void *workspace;             /* device scratch of >= sigma_scan_bwd_workspace_bytes() bytes,
+                                    16-byte aligned; may be NULL when that function returns 0.
+                                    Holds the per-workgroup dB/dC partials; contents are garbage
+                                    after the call.  Provided by the caller because the callee
+                                    never allocates. */
+    int64_t workspace_bytes;
     int64_t dout_batch_stride, dout_d_stride;
     int64_t du_batch_stride, du_d_stride;
     int64_t ddelta_batch_stride, ddelta_d_stride;
@@ -114,8 +121,12 @@ typedef struct sigma_scan_bwd_params {
 /* Forward: out, x <- scan(u, delta, A, B, C, D, delta_bias). */
 int sigma_selective_scan_fwd(const sigma_scan_fwd_params *params, void *stream);
 
-/* Backward: du, ddelta written; dA, dB, dC, dD, ddelta_bias accumulated (+=). */
+/* Backward: du, ddelta, dB, dC written; dA, dD, ddelta_bias accumulated (+=). */
 int sigma_selective_scan_bwd(const sigma_scan_bwd_params *params, void *stream);
+
+/* Scratch bytes sigma_selective_scan_bwd needs for this problem under the current options
+ * (0 when one workgroup covers a whole (batch, group)); negative = invalid params. */
+int64_t sigma_scan_bwd_workspace_bytes(const sigma_scan_bwd_params *params);
 
 /* Thread-local description of the last non-zero status returned on this thread. */
 const char *sigma_scan_last_error(void);

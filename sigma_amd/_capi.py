@@ -13,7 +13,7 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libsigma_hip.so")
 
-SIGMA_SCAN_ABI_VERSION = 1
+SIGMA_SCAN_ABI_VERSION = 2
 SIGMA_SCAN_CHUNK = 2048
 SIGMA_SCAN_MAX_DSTATE = 256
 
@@ -48,6 +48,7 @@ class BwdParams(ctypes.Structure):
         ("dout", ctypes.c_void_p), ("du", ctypes.c_void_p), ("ddelta", ctypes.c_void_p),
         ("dA", ctypes.c_void_p), ("dB", ctypes.c_void_p), ("dC", ctypes.c_void_p),
         ("dD", ctypes.c_void_p), ("ddelta_bias", ctypes.c_void_p),
+        ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_int64),
         ("dout_batch_stride", ctypes.c_int64), ("dout_d_stride", ctypes.c_int64),
         ("du_batch_stride", ctypes.c_int64), ("du_d_stride", ctypes.c_int64),
         ("ddelta_batch_stride", ctypes.c_int64), ("ddelta_d_stride", ctypes.c_int64),
@@ -61,6 +62,7 @@ class BwdParams(ctypes.Structure):
 EXPORTED_SYMBOLS = (
     "sigma_selective_scan_fwd",
     "sigma_selective_scan_bwd",
+    "sigma_scan_bwd_workspace_bytes",
     "sigma_scan_last_error",
     "sigma_scan_abi_version",
     "sigma_scan_set_option",
@@ -91,6 +93,8 @@ def load() -> ctypes.CDLL:
     lib.sigma_selective_scan_fwd.restype = ctypes.c_int
     lib.sigma_selective_scan_bwd.argtypes = [P(BwdParams), ctypes.c_void_p]
     lib.sigma_selective_scan_bwd.restype = ctypes.c_int
+    lib.sigma_scan_bwd_workspace_bytes.argtypes = [P(BwdParams)]
+    lib.sigma_scan_bwd_workspace_bytes.restype = ctypes.c_int64
     lib.sigma_scan_last_error.argtypes = []
     lib.sigma_scan_last_error.restype = ctypes.c_char_p
     lib.sigma_scan_abi_version.argtypes = []

@@ -205,6 +205,17 @@ int sigma_selective_scan_fwd(const sigma_scan_fwd_params* p, void* stream) {
     return SIGMA_OK;
 }
 
+int64_t sigma_scan_bwd_workspace_bytes(const sigma_scan_bwd_params* q) {
+    if (!q) { fail(SIGMA_ERR_NULL_ARG, "params is NULL"); return -1; }
+    const sigma_scan_fwd_params* p = &q->fwd;
+    if (check_fwd(p, false, false)) return -1;
+    if (p->batch == 0 || p->seqlen == 0) return 0;
+    const Plan pl = plan_bwd(p);
+    const int P = (p->dim / p->n_groups) / pl.waves;
+    if (P <= 1) return 0;
+    return (int64_t)2 * P * p->batch * p->n_groups * (int64_t)p->dstate * p->seqlen * (int64_t)sizeof(float);
+}
+
 int sigma_selective_scan_bwd(const sigma_scan_bwd_params* q, void* stream) {
     if (!q) return fail(SIGMA_ERR_NULL_ARG, "params is NULL");
     const sigma_scan_fwd_params* p = &q->fwd;
@@ -219,6 +230,14 @@ int sigma_selective_scan_bwd(const sigma_scan_bwd_params* q, void* stream) {
         return fail(SIGMA_ERR_NULL_ARG, "dD / ddelta_bias must be given exactly when D / delta_bias are");
     const Plan pl = plan_bwd(p);
     if (pl.lds > 160 * 1024) return fail(SIGMA_ERR_BAD_SHAPE, "LDS budget exceeded (%zu B)", pl.lds);
+    const int P = (p->dim / p->n_groups) / pl.waves;
+    const int64_t slab = (int64_t)P * p->batch * p->n_groups * (int64_t)p->dstate * p->seqlen;
+    if (P > 1) {
+        if (!q->workspace || q->workspace_bytes < 2 * slab * (int64_t)sizeof(float))
+            return fail(SIGMA_ERR_NULL_ARG, "workspace of %lld bytes required (got %lld)",
+                        (long long)(2 * slab * (int64_t)sizeof(float)), (long long)q->workspace_bytes);
+        if (!aligned_to(q->workspace, 16)) return fail(SIGMA_ERR_BAD_STRIDE, "workspace must be 16-byte aligned");
+    }
     const size_t al = 4 * (size_t)elem_size(p->io_dtype);
     bool vec = vec_ok_fwd(p, false) && aligned_to(q->dout, al) && aligned_to(q->du, al) && aligned_to(q->ddelta, al) &&
                q->dout_batch_stride % 4 == 0 && q->dout_d_stride % 4 == 0 && q->du_batch_stride % 4 == 0 &&
@@ -234,6 +253,9 @@ int sigma_selective_scan_bwd(const sigma_scan_bwd_params* q, void* stream) {
     a.dA_ds = q->dA_d_stride; a.dA_ns = q->dA_dstate_stride;
     a.dB_bs = q->dB_batch_stride; a.dB_gs = q->dB_group_stride; a.dB_ns = q->dB_dstate_stride;
     a.dC_bs = q->dC_batch_stride; a.dC_gs = q->dC_group_stride; a.dC_ns = q->dC_dstate_stride;
+    a.P = P;
+    a.ws_dB = P > 1 ? static_cast<float*>(q->workspace) : nullptr;
+    a.ws_dC = P > 1 ? static_cast<float*>(q->workspace) + slab : nullptr;
     hipError_t e = sigma::launch_scan_bwd(a, p->io_dtype, pl.items, pl.waves, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(SIGMA_ERR_LAUNCH, "scan_bwd launch failed: %s", hipGetErrorString(e));
     return SIGMA_OK;

@@ -13,9 +13,12 @@
 //     e = a * dx ("what flows to the element on the left");
 //   * the reverse scan across lanes is a DPP row_shl scan + uniform row-head fix-up;
 //   * dB / dC are reduced over the workgroup's rows in LDS (ds_add_f32 into a swizzled
-//     [state][k][lane] tile) and leave the CU as ONE coalesced float atomic per (n, l) per
-//     workgroup -- the reference issues one global atomic per row (192 per element at
-//     stage 0); dA / dD / ddelta_bias are wave-reduced with DPP and hit memory once per row.
+//     [state][k][lane] tile); each workgroup then writes ONE plain coalesced partial per
+//     (n, l) into its slab of a caller-provided workspace and reduce_partials_kernel sums the
+//     P = rows_per_group / rows_per_workgroup slabs in a fixed order -- deterministic, and no
+//     device-scope float atomics (the reference issues one global atomicAdd per row: 192
+//     per element at stage 0).  dA / dD / ddelta_bias are wave-reduced with DPP and hit
+//     memory once per row.
 #include "scan_device.h"
 #include "scan_launch.h"
 
@@ -256,17 +259,32 @@ scan_bwd_kernel(const BwdArgs q) {
                     }
                 }
                 __syncthreads();
-                // ---- flush the workgroup-reduced dB/dC block: one coalesced atomic per (n, l)
-                for (int idx = tid; idx < NB * G::TILE; idx += blockDim.x) {
-                    const int nn = idx / G::TILE;
-                    const int li = idx - nn * G::TILE;
-                    const int n = nb0 + nn;
-                    const int l = l0 + li;
-                    if (n < N && l < L) {
-                        const int ln = li / T, k = li % T;
-                        const int so = (nn * T + k) * 64 + (ln ^ ((k * SWZ) & 63));
-                        atomicAdd(dBg + (long)n * q.dB_ns + l, sdB[so]);
-                        atomicAdd(dCg + (long)n * q.dC_ns + l, sdC[so]);
+                // ---- flush the workgroup-reduced dB/dC block with plain coalesced stores: straight
+                // into dB/dC when this workgroup owns the whole group, else into its private slab
+                // of the partial workspace (summed by reduce_partials_kernel; device-scope float
+                // atomics run at ~0.16 TB/s on this chip and were 70 % of the first version's time)
+                {
+                    float* __restrict__ outB;
+                    float* __restrict__ outC;
+                    long nsB, nsC;
+                    if (q.P == 1) {
+                        outB = dBg; outC = dCg; nsB = q.dB_ns; nsC = q.dC_ns;
+                    } else {
+                        const int pidx = (row0 - g * p.rows_per_group) / nwaves;
+                        const long slab = (((long)pidx * p.batch + b) * p.G + g) * (long)N * L;
+                        outB = q.ws_dB + slab; outC = q.ws_dC + slab; nsB = L; nsC = L;
+                    }
+                    for (int idx = tid; idx < NB * G::TILE; idx += blockDim.x) {
+                        const int nn = idx / G::TILE;
+                        const int li = idx - nn * G::TILE;
+                        const int n = nb0 + nn;
+                        const int l = l0 + li;
+                        if (n < N && l < L) {
+                            const int ln = li / T, k = li % T;
+                            const int so = (nn * T + k) * 64 + (ln ^ ((k * SWZ) & 63));
+                            outB[(long)n * nsB + l] = sdB[so];
+                            outC[(long)n * nsC + l] = sdC[so];
+                        }
                     }
                 }
             }
@@ -298,6 +316,44 @@ scan_bwd_kernel(const BwdArgs q) {
         atomicAdd(q.dA + (long)r * q.dA_ds + (long)n * q.dA_ns, sdA[wave * N + n]);
 }
 
+// out[b, g, n, l] = sum_p ws[p][b][g][n][l]   (deterministic order; 4 elements per thread)
+__global__ void __launch_bounds__(256)
+reduce_partials_kernel(const float* __restrict__ wsB, const float* __restrict__ wsC, float* __restrict__ dB,
+                       float* __restrict__ dC, int P, int batch, int G, int N, int L, long dB_bs, long dB_gs,
+                       long dB_ns, long dC_bs, long dC_gs, long dC_ns) {
+    const long per = (long)batch * G * N * L;
+    const long nvec = (per + 3) / 4;
+    for (long v = (long)blockIdx.x * blockDim.x + threadIdx.x; v < nvec; v += (long)gridDim.x * blockDim.x) {
+        const long e0 = v * 4;
+        float accB[4] = {0.f, 0.f, 0.f, 0.f}, accC[4] = {0.f, 0.f, 0.f, 0.f};
+        const bool full = (e0 + 3 < per) && ((L & 3) == 0);
+        if (full) {
+            for (int pp = 0; pp < P; ++pp) {
+                const float4 tb = *reinterpret_cast<const float4*>(wsB + pp * per + e0);
+                const float4 tc = *reinterpret_cast<const float4*>(wsC + pp * per + e0);
+                accB[0] += tb.x; accB[1] += tb.y; accB[2] += tb.z; accB[3] += tb.w;
+                accC[0] += tc.x; accC[1] += tc.y; accC[2] += tc.z; accC[3] += tc.w;
+            }
+        } else {
+            for (int pp = 0; pp < P; ++pp)
+                for (int i = 0; i < 4; ++i)
+                    if (e0 + i < per) { accB[i] += wsB[pp * per + e0 + i]; accC[i] += wsC[pp * per + e0 + i]; }
+        }
+        for (int i = 0; i < 4; ++i) {
+            const long e = e0 + i;
+            if (e >= per) break;
+            const int l = (int)(e % L);
+            const long t = e / L;
+            const int n = (int)(t % N);
+            const long t2 = t / N;
+            const int g = (int)(t2 % G);
+            const int b = (int)(t2 / G);
+            dB[b * dB_bs + g * dB_gs + n * dB_ns + l] = accB[i];
+            dC[b * dC_bs + g * dC_gs + n * dC_ns + l] = accC[i];
+        }
+    }
+}
+
 template <typename io_t, int T>
 static hipError_t launch_bwd_t(const BwdArgs& a, int nwaves, hipStream_t stream) {
     const size_t lds = bwd_lds_bytes(T, nwaves, a.f.N);
@@ -309,6 +365,15 @@ static hipError_t launch_bwd_t(const BwdArgs& a, int nwaves, hipStream_t stream)
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(nwaves * 64), lds, stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || a.P == 1) return e;
+    const long per = (long)a.f.batch * a.f.G * a.f.N * a.f.L;
+    long blocks = (per / 4 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a.ws_dB, a.ws_dC, a.dB,
+                       a.dC, a.P, a.f.batch, a.f.G, a.f.N, a.f.L, a.dB_bs, a.dB_gs, a.dB_ns, a.dC_bs, a.dC_gs,
+                       a.dC_ns);
     return hipGetLastError();
 }
 

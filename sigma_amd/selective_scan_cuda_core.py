@@ -130,8 +130,9 @@ def bwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B: torch.Tensor, 
     du = torch.empty_like(u)                                         # :329-337
     ddelta = torch.empty_like(delta)
     dA = torch.zeros_like(A)
-    dB = torch.zeros_like(B, dtype=torch.float32)
-    dC = torch.zeros_like(C, dtype=torch.float32)
+    # fully written by the library (deterministic two-stage sum), so no zero fill is needed
+    dB = torch.empty_like(B, dtype=torch.float32) if batch > 0 and seqlen > 0 else torch.zeros_like(B, dtype=torch.float32)
+    dC = torch.empty_like(C, dtype=torch.float32) if batch > 0 and seqlen > 0 else torch.zeros_like(C, dtype=torch.float32)
     dD = torch.zeros_like(D_) if D_ is not None else None
     ddelta_bias = torch.zeros_like(delta_bias_) if delta_bias_ is not None else None
     if batch > 0 and seqlen > 0:
@@ -145,6 +146,12 @@ def bwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B: torch.Tensor, 
         bp.dA_d_stride, bp.dA_dstate_stride = dA.stride(0), dA.stride(1)
         bp.dB_batch_stride, bp.dB_group_stride, bp.dB_dstate_stride = dB.stride(0), dB.stride(1), dB.stride(2)
         bp.dC_batch_stride, bp.dC_group_stride, bp.dC_dstate_stride = dC.stride(0), dC.stride(1), dC.stride(2)
+        ws_bytes = int(lib.sigma_scan_bwd_workspace_bytes(ctypes.byref(bp)))
+        _check(ws_bytes >= 0, "selective_scan_bwd: " + _capi.last_error())
+        workspace = None
+        if ws_bytes > 0:                                 # per-workgroup dB/dC partials (caching allocator)
+            workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=u.device)
+            bp.workspace, bp.workspace_bytes = _ptr(workspace), ws_bytes
         with torch.cuda.device(u.device):
             stream = torch.cuda.current_stream(u.device).cuda_stream
             _capi.check(lib.sigma_selective_scan_bwd(ctypes.byref(bp), ctypes.c_void_p(stream)), "selective_scan_bwd")

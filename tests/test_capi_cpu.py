@@ -19,7 +19,7 @@ def test_library_loads_and_abi_version():
 
 def test_exports_every_declared_symbol():
     header = open(os.path.join(ROOT, "include", "sigma_scan.h")).read()
-    declared = set(re.findall(r"^\s*(?:const\s+char\s*\*\s*|int\s+)(sigma_\w+)\s*\(", header, flags=re.M))
+    declared = set(re.findall(r"^\s*(?:const\s+char\s*\*\s*|int\s+|int64_t\s+)(sigma_\w+)\s*\(", header, flags=re.M))
     assert declared == set(_capi.EXPORTED_SYMBOLS), declared ^ set(_capi.EXPORTED_SYMBOLS)
     lib = _capi.load()
     for name in declared:
@@ -27,9 +27,9 @@ def test_exports_every_declared_symbol():
 
 
 def test_struct_layout_matches_header():
-    # 8 int32 + 9 pointers + 14 int64 ; bwd adds 8 pointers + 14 int64
+    # 8 int32 + 9 pointers + 14 int64 ; bwd adds 9 pointers + 15 int64
     assert ctypes.sizeof(_capi.FwdParams) == 8 * 4 + 9 * 8 + 14 * 8
-    assert ctypes.sizeof(_capi.BwdParams) == ctypes.sizeof(_capi.FwdParams) + 8 * 8 + 14 * 8
+    assert ctypes.sizeof(_capi.BwdParams) == ctypes.sizeof(_capi.FwdParams) + 9 * 8 + 15 * 8
 
 
 def _params(**kw):
@@ -83,6 +83,8 @@ def test_options_and_launch_plan():
     bp.fwd = p
     assert lib.sigma_scan_bwd_plan(ctypes.byref(bp), ctypes.byref(plan)) == 0
     assert plan[0] in (4, 8) and plan[3] <= 160 * 1024
+    # 12 rows per group, 4 per workgroup -> 3 partial slabs of (B, G, N, L) for each of dB, dC
+    assert lib.sigma_scan_bwd_workspace_bytes(ctypes.byref(bp)) == 2 * 3 * 2 * 2 * 8 * 372 * 4
 
 
 def test_operator_module_raises_without_gpu_tensors():
