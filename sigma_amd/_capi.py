@@ -11,7 +11,8 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsigma_hip.so")
+# SIGMA_HIP_LIB lets a benchmark A/B an experimental build of the same ABI; default is the in-tree library
+LIB_PATH = os.environ.get("SIGMA_HIP_LIB") or os.path.join(_HERE, "lib", "libsigma_hip.so")
 
 SIGMA_SCAN_ABI_VERSION = 2
 SIGMA_SCAN_CHUNK = 2048

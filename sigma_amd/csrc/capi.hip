@@ -254,6 +254,9 @@ int sigma_selective_scan_bwd(const sigma_scan_bwd_params* q, void* stream) {
     a.dB_bs = q->dB_batch_stride; a.dB_gs = q->dB_group_stride; a.dB_ns = q->dB_dstate_stride;
     a.dC_bs = q->dC_batch_stride; a.dC_gs = q->dC_group_stride; a.dC_ns = q->dC_dstate_stride;
     a.P = P;
+    a.out_vec_ok = (aligned_to(q->dB, 16) && aligned_to(q->dC, 16) && q->dB_batch_stride % 4 == 0 &&
+                    q->dB_group_stride % 4 == 0 && q->dB_dstate_stride % 4 == 0 && q->dC_batch_stride % 4 == 0 &&
+                    q->dC_group_stride % 4 == 0 && q->dC_dstate_stride % 4 == 0) ? 1 : 0;
     a.ws_dB = P > 1 ? static_cast<float*>(q->workspace) : nullptr;
     a.ws_dC = P > 1 ? static_cast<float*>(q->workspace) + slab : nullptr;
     hipError_t e = sigma::launch_scan_bwd(a, p->io_dtype, pl.items, pl.waves, static_cast<hipStream_t>(stream));

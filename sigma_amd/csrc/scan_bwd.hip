@@ -30,16 +30,14 @@ scan_bwd_kernel(const BwdArgs q) {
     using G = TileGeom<T>;
     constexpr int NB = kStateBlock;
     constexpr int TPC = 2048 / G::TILE;               // tiles per checkpoint chunk
-    constexpr int SWZ = 64 / T;                       // lane swizzle step of the dB/dC tile
     const FwdArgs& p = q.f;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int nwaves = blockDim.x >> 6;
     const int N = p.N, L = p.L;
     float* sB = smem;
     float* sC = sB + NB * G::ROW;
-    float* sdB = sC + NB * G::ROW;                    // [NB][T][64] swizzled
-    float* sdC = sdB + NB * T * 64;
-    float* sX0 = sdC + NB * T * 64;                   // [nwaves][TPC][N] state at tile start
+    float* sRed = sC + NB * G::ROW;                   // [nwaves][2][TILE] per-row dB/dC terms of one state
+    float* sX0 = sRed + nwaves * 2 * G::TILE;         // [nwaves][TPC][N] state at tile start
     float* sR = sX0 + nwaves * TPC * N;               // [nwaves][N] reverse carry a*dx of the tile to the right
     float* sdA = sR + nwaves * N;                     // [nwaves][N]
     float* sA = sdA + nwaves * N;                     // [nwaves][N] A[r, n]
@@ -70,6 +68,8 @@ scan_bwd_kernel(const BwdArgs q) {
     const float Dd = p.D ? p.D[r] : 0.0f;
     const float* __restrict__ x_row = p.x ? p.x + ((long)b * p.dim + r) * (long)p.n_chunks * 2 * N : nullptr;
 
+    const long ws_slab = (q.P > 1)
+        ? ((((long)((row0 - g * p.rows_per_group) / nwaves) * p.batch + b) * p.G + g) * (long)N * L) : 0;
     for (int n = lane; n < N; n += 64) {
         sR[wave * N + n] = 0.0f; sdA[wave * N + n] = 0.0f; sA[wave * N + n] = A_row[(long)n * p.A_ns];
     }
@@ -148,9 +148,9 @@ scan_bwd_kernel(const BwdArgs q) {
         for (int j = ntc - 1; j >= 0; --j) {
             const int l0 = cl0 + j * G::TILE;
             const int lbase = l0 + lane * T;
-            float dl[T], dlu[T], uu[T], gg[T], sdxB[T], sAx[T];
+            float dl[T], dlu[T], gg[T], sdxB[T], sAx[T];
             {
-                float dv[T];
+                float dv[T], uu[T];
                 load_items<io_t, T>(u_row, lbase, L, vec, uu);
                 load_items<io_t, T>(d_row, lbase, L, vec, dv);
                 load_items<io_t, T>(g_row, lbase, L, vec, gg);
@@ -184,8 +184,6 @@ scan_bwd_kernel(const BwdArgs q) {
                     const int off = nn * G::ROW + (l4 / T) * G::LSTR + (l4 % T);
                     *reinterpret_cast<float4*>(sB + off) = make_float4(bv[0], bv[1], bv[2], bv[3]);
                     *reinterpret_cast<float4*>(sC + off) = make_float4(cv[0], cv[1], cv[2], cv[3]);
-                    *reinterpret_cast<float4*>(sdB + idx * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
-                    *reinterpret_cast<float4*>(sdC + idx * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
                 }
                 __syncthreads();
 
@@ -234,10 +232,20 @@ scan_bwd_kernel(const BwdArgs q) {
                     const float en = wave_next_lane(e, 0.0f);
                     e = fmaf(pn, sR[wave * N + n], en);          // e entering from the right
                     float dAp = 0.0f;
+                    // Reverse replay.  Each lane's per-row terms of dB[n, l] / dC[n, l] go straight to
+                    // this wave's LDS slab (natural l order), four at a time, to keep registers free.
+                    // Then the workgroup's rows are reduced: the first 2*TILE/4 threads add the slabs
+                    // in a fixed order and write ONE coalesced float4 per 4 elements -- straight into
+                    // dB/dC when this workgroup owns the whole group, else into its slab of the
+                    // partial workspace (summed by reduce_partials_kernel).  ds_add_f32 was measured
+                    // at ~1000 cycles per wave instruction on gfx950 and global float atomics at
+                    // ~0.16 TB/s; plain LDS traffic + two barriers per state is far cheaper.
+                    float* __restrict__ slab = sRed + wave * 2 * G::TILE + lane * T;
 #pragma unroll
                     for (int qq = T / 4 - 1; qq >= 0; --qq) {
                         const float4 bv = pB[qq];                // B again: cheaper than T live registers
                         const float bq[4] = {bv.x, bv.y, bv.z, bv.w};
+                        float vb[4], vc[4];
 #pragma unroll
                         for (int jj = 3; jj >= 0; --jj) {
                             const int k = 4 * qq + jj;
@@ -246,53 +254,55 @@ scan_bwd_kernel(const BwdArgs q) {
                             const float t = dx * (xs[k] - bb[k]);    // dx * a_k * x_{k-1}
                             sAx[k] = fmaf(An, t, sAx[k]);
                             dAp = fmaf(dl[k], t, dAp);
-                            const int so = (nn * T + k) * 64 + (lane ^ ((k * SWZ) & 63));
-                            atomicAdd(sdB + so, dx * dlu[k]);
-                            atomicAdd(sdC + so, gg[k] * xs[k]);
+                            vb[jj] = dx * dlu[k];                    // this row's term of dB[n, l]
+                            vc[jj] = gg[k] * xs[k];                  // this row's term of dC[n, l]
                             e = a[k] * dx;
                         }
+                        *reinterpret_cast<float4*>(slab + 4 * qq) = make_float4(vb[0], vb[1], vb[2], vb[3]);
+                        *reinterpret_cast<float4*>(slab + G::TILE + 4 * qq) = make_float4(vc[0], vc[1], vc[2], vc[3]);
                     }
                     dAp = wave_sum(dAp);
                     if (lane == 0) {
                         sR[wave * N + n] = e;                    // a*dx of the tile's first element
                         sdA[wave * N + n] += dAp;
                     }
-                }
-                __syncthreads();
-                // ---- flush the workgroup-reduced dB/dC block with plain coalesced stores: straight
-                // into dB/dC when this workgroup owns the whole group, else into its private slab
-                // of the partial workspace (summed by reduce_partials_kernel; device-scope float
-                // atomics run at ~0.16 TB/s on this chip and were 70 % of the first version's time)
-                {
-                    float* __restrict__ outB;
-                    float* __restrict__ outC;
-                    long nsB, nsC;
-                    if (q.P == 1) {
-                        outB = dBg; outC = dCg; nsB = q.dB_ns; nsC = q.dC_ns;
-                    } else {
-                        const int pidx = (row0 - g * p.rows_per_group) / nwaves;
-                        const long slab = (((long)pidx * p.batch + b) * p.G + g) * (long)N * L;
-                        outB = q.ws_dB + slab; outC = q.ws_dC + slab; nsB = L; nsC = L;
-                    }
-                    for (int idx = tid; idx < NB * G::TILE; idx += blockDim.x) {
-                        const int nn = idx / G::TILE;
-                        const int li = idx - nn * G::TILE;
-                        const int n = nb0 + nn;
-                        const int l = l0 + li;
-                        if (n < N && l < L) {
-                            const int ln = li / T, k = li % T;
-                            const int so = (nn * T + k) * 64 + (ln ^ ((k * SWZ) & 63));
-                            outB[(long)n * nsB + l] = sdB[so];
-                            outC[(long)n * nsC + l] = sdC[so];
+                    __syncthreads();
+                    for (int t4 = tid; t4 < 2 * G::TILE / 4; t4 += blockDim.x) {
+                        const int c = t4 / (G::TILE / 4);           // 0: dB, 1: dC
+                        const int l4 = (t4 - c * (G::TILE / 4)) * 4;
+                        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+                        for (int w = 0; w < nwaves; ++w) {
+                            const float4 v = *reinterpret_cast<const float4*>(sRed + w * 2 * G::TILE + c * G::TILE + l4);
+                            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+                        }
+                        const int l = l0 + l4;
+                        if (l < L) {
+                            float* __restrict__ dst;
+                            bool vst;
+                            if (q.P == 1) {
+                                dst = (c == 0 ? dBg + (long)n * q.dB_ns : dCg + (long)n * q.dC_ns) + l;
+                                vst = q.out_vec_ok != 0;
+                            } else {
+                                dst = (c == 0 ? q.ws_dB : q.ws_dC) + ws_slab + (long)n * L + l;
+                                vst = (L & 3) == 0;
+                            }
+                            if (vst && l + 3 < L) {
+                                *reinterpret_cast<float4*>(dst) = acc;
+                            } else {
+                                const float av[4] = {acc.x, acc.y, acc.z, acc.w};
+                                for (int i = 0; i < 4; ++i) if (l + i < L) dst[i] = av[i];
+                            }
                         }
                     }
+                    __syncthreads();
                 }
             }
             // ---- per-element results
-            float duv[T], ddv[T], dv2[T];
-            // softplus' = sigmoid(raw): re-read delta (L2-resident) instead of holding T registers
-            // across the whole state loop
+            float duv[T], ddv[T], dv2[T], uu[T];
+            // softplus' = sigmoid(raw) and the u factors: re-read delta and u (L2-resident) instead
+            // of holding 2T registers across the whole state loop
             load_items<io_t, T>(d_row, lbase, L, vec, dv2);
+            load_items<io_t, T>(u_row, lbase, L, vec, uu);
 #pragma unroll
             for (int k = 0; k < T; ++k) {
                 duv[k] = fmaf(Dd, gg[k], dl[k] * sdxB[k]);

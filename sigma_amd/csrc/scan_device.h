@@ -256,6 +256,7 @@ struct BwdArgs {
     float* dA; float* dB; float* dC; float* dD; float* dbias;
     float* ws_dB; float* ws_dC;     // [P][batch][G][N][L] per-workgroup partials (P > 1)
     int P;                          // workgroups per (batch, group) = rows_per_group / nwaves
+    int out_vec_ok;                 // dB/dC rows are 16-byte aligned (float4 stores legal when P == 1)
     long g_bs, g_ds, du_bs, du_ds, dd_bs, dd_ds, dA_ds, dA_ns;
     long dB_bs, dB_gs, dB_ns, dC_bs, dC_gs, dC_ns;
 };

@@ -11,13 +11,13 @@ inline size_t fwd_lds_bytes(int T, int nwaves, int N) {
     return sizeof(float) * (2 * kStateBlock * row + 2 * (size_t)nwaves * N);
 }
 
-// backward: B, C tiles (padded, lane-blocked) + dB, dC accumulators (swizzled, [state][k][lane])
+// backward: B, C tiles (padded, lane-blocked) + per-wave dB/dC term slabs ([wave][2][TILE])
 // + per-wave scratch: tile-start states for every tile of a 2048 chunk, reverse carry, dA partials
 inline size_t bwd_lds_bytes(int T, int nwaves, int N) {
     const int pad = (T >= 8) ? 4 : 0;
     const size_t row = (size_t)kWave * (T + pad);
     const int tiles_per_chunk = 2048 / (kWave * T);
-    return sizeof(float) * (2 * kStateBlock * row + 2 * kStateBlock * (size_t)T * kWave +
+    return sizeof(float) * (2 * kStateBlock * row + 2 * (size_t)nwaves * kWave * T +
                             (size_t)nwaves * N * (tiles_per_chunk + 3));
 }
 
