@@ -1,0 +1,269 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of Sigma's training step (fwd + bwd + AdamW) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W            (N = 1 default)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json `metric`, configs[2]/[3]): sigma_small, synthetic RGB-X pairs of
+3x480x640 (+ labels of 40 classes, NYU shape), fp32 like the reference, one process per GPU,
+DistributedDataParallel over RCCL for N > 1 (gradient all-reduce only; the forward is per-image
+data parallel).  Per-GPU batch is fixed (weak scaling); at N = 1 the global batch equals the
+reference's config batch_size = 8 (configs/config_nyu.py:101).
+
+One step = loss = model(rgb, x, label); zero_grad; backward; AdamW step; the scalar loss
+all-reduce of train.py:168.  W untimed steps, then exactly K steps between barrier +
+synchronize pairs; the slowest rank's time counts.  Rank 0 prints ONE JSON line.
+
+Extra objects on that line:
+  roofline     -- dominant HIP kernel (largest share of scan time in the timed region):
+                  achieved = SURVEY 8(d) algorithmic bytes of that launch shape / mean launch
+                  duration, measured with HIP events on the launch stream inside the timed steps
+  cpu_baseline -- the CPU oracle (C port of the reference's selective_scan_ref + its adjoint)
+                  timed on this host's cores on a bounded sample, in images/s
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X spec (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=8, help="per-GPU batch of RGB-X pairs")
+    ap.add_argument("--backbone", default="sigma_small")
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--classes", type=int, default=40)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU oracle work")
+    ap.add_argument("--kernel-report", default="", help="write the per-kernel-shape table (json) here")
+    return ap.parse_args()
+
+
+def group_weight(module: nn.Module, lr: float):
+    """Optimizer groups of the reference (utils/init_func.py:33-58): Linear/conv weights decay,
+    norms and biases do not; raw nn.Parameters owned directly by the Mamba blocks end up in no
+    group and are therefore never stepped -- reproduced on purpose."""
+    decay, no_decay = [], []
+    for m in module.modules():
+        if isinstance(m, (nn.Linear, nn.Conv1d, nn.Conv2d, nn.Conv3d, nn.ConvTranspose2d)):
+            decay.append(m.weight)
+            if m.bias is not None:
+                no_decay.append(m.bias)
+        elif isinstance(m, (nn.LayerNorm, nn.GroupNorm, nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d)):
+            if m.weight is not None:
+                no_decay.append(m.weight)
+            if m.bias is not None:
+                no_decay.append(m.bias)
+    return [dict(params=decay, lr=lr), dict(params=no_decay, weight_decay=0.0, lr=lr)]
+
+
+class KernelTimer:
+    """HIP-event timing of every scan launch inside the timed region, on the launch stream."""
+
+    def __init__(self):
+        self.enabled = False
+        self.records = []       # (kind, shape_key, start_event, end_event)
+
+    def __call__(self, kind, key, launch):
+        if not self.enabled:
+            return launch()
+        s = torch.cuda.Event(enable_timing=True)
+        e = torch.cuda.Event(enable_timing=True)
+        s.record()
+        out = launch()
+        e.record()
+        self.records.append((kind, key, s, e))
+        return out
+
+    def table(self):
+        agg = {}
+        for kind, key, s, e in self.records:
+            d = agg.setdefault((kind, key), [0, 0.0])
+            d[0] += 1
+            d[1] += s.elapsed_time(e) * 1e-3
+        return agg
+
+
+def scan_bytes(kind, key):
+    B, KD, L, N, G, es = key
+    if kind == "fwd":       # SURVEY.md 8(d), training: + checkpoint write
+        return es * 3 * B * KD * L + es * 2 * B * G * N * L + 4 * (KD * N + 2 * KD) + 4 * B * KD * ((L + 2047) // 2048) * 2 * N
+    return es * 5 * B * KD * L + es * 4 * B * G * N * L
+
+
+def cpu_baseline(backbone, H, W, budget_s):
+    """Images/s of the CPU path's selective scans alone (upper bound of a full CPU step):
+    oracle fwd + bwd on one group-slice of every distinct scan shape of the model at batch 1,
+    scaled by groups and call counts."""
+    from oracle import scan_oracle as so
+    E = 128 if backbone == "sigma_base" else 96
+    depths = [2, 2, 9, 2] if backbone == "sigma_tiny" else [2, 2, 27, 2]
+    shapes = []            # (calls, KD, L, N, G)
+    h, w = H // 4, W // 4
+    for i in range(4):
+        C = E * 2 ** i
+        d, L = 2 * C, h * w
+        shapes.append((2 * depths[i], 4 * d, L, 16, 4))          # encoder, both modalities
+        shapes.append((2, d, L, 4, 1))                           # CroMB
+        shapes.append((1, 2 * d, 2 * L, 4, 2))                   # ConMB
+        if i < 3:
+            shapes.append((4, 4 * d, L, 4, 4))                   # decoder level
+        h, w = (h + 1) // 2, (w + 1) // 2
+    total_updates = sum(c * kd * L * N for c, kd, L, N, _ in shapes)
+    per_shape_budget = budget_s / len(shapes)
+    t_total, sampled = 0.0, 0
+    g = torch.Generator().manual_seed(0)
+    for calls, KD, L, N, G in shapes:
+        rows = KD // G                                            # one group
+        frac = min(1.0, max(8, int(rows * per_shape_budget / (4e-8 * rows * L * N * 4 + 1e-9))) / rows)
+        r = max(1, int(rows * frac))
+        u = torch.randn(1, r, L, generator=g)
+        delta = 0.5 * torch.randn(1, r, L, generator=g)
+        A = -torch.arange(1, N + 1, dtype=torch.float32).repeat(r, 1)
+        Bm, Cm = torch.randn(1, 1, N, L, generator=g), torch.randn(1, 1, N, L, generator=g)
+        D, bias = torch.ones(r), torch.full((r,), -4.0)
+        t0 = time.perf_counter()
+        out = so.selective_scan_oracle(u, delta, A, Bm, Cm, D, bias, True)
+        so.selective_scan_oracle_bwd(u, delta, A, Bm, Cm, D, bias, out, True)
+        dt = time.perf_counter() - t0
+        t_total += dt * (KD / r) * calls
+        sampled += r * L * N
+    return dict(value=1.0 / t_total, unit="images/s", cores=so.num_threads(), kind="port",
+                sample=(f"oracle/scan_oracle.c fwd+bwd (OpenMP, {so.num_threads()} threads) on a row slice of each of the "
+                        f"{len(shapes)} distinct scan shapes of {backbone} @{H}x{W}, batch 1 "
+                        f"({sampled / total_updates:.1%} of one image's state updates), scaled by rows and call counts; "
+                        "scans only, so an upper bound on the CPU path"))
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
+
+    from sigma_amd import selective_scan_cuda_core as core
+    from sigma_amd.models.builder import EncoderDecoder
+
+    timer = KernelTimer()
+    core.set_launch_hook(timer)
+
+    cfg = types.SimpleNamespace(backbone=a.backbone, decoder="MambaDecoder", num_classes=a.classes,
+                                image_height=a.height, image_width=a.width, pretrained_model=None, bn_eps=1e-3,
+                                bn_momentum=0.1)
+    torch.manual_seed(rank)                                  # train.py:59-63: seed = local rank
+    cwd = os.getcwd()
+    os.chdir("/tmp")
+    try:
+        import contextlib
+        import io
+        with contextlib.redirect_stdout(io.StringIO()):      # the (absent) pretrained checkpoint message
+            model = EncoderDecoder(cfg, criterion=nn.CrossEntropyLoss(reduction="mean", ignore_index=255),
+                                   norm_layer=nn.BatchNorm2d)
+    finally:
+        os.chdir(cwd)
+    model.to(dev).train()
+    opt = torch.optim.AdamW(group_weight(model, 6e-5), lr=6e-5, betas=(0.9, 0.999), weight_decay=0.01)
+    net = model
+    if world > 1:
+        net = nn.parallel.DistributedDataParallel(model, device_ids=[local], output_device=local,
+                                                  find_unused_parameters=False)   # train.py:107
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    rgb = torch.randn(a.batch, 3, a.height, a.width, generator=g).to(dev)
+    mx = torch.randn(a.batch, 3, a.height, a.width, generator=g).to(dev)
+    label = torch.randint(0, a.classes, (a.batch, a.height, a.width), generator=g).to(dev)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = net(rgb, mx, label)
+        if world > 1:                                        # train.py:168 (logging all-reduce)
+            red = loss.detach().clone()
+            dist.all_reduce(red, op=dist.ReduceOp.SUM)
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(a.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    timer.enabled = False
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        table = timer.table()
+        rows = []
+        for (kind, key), (n, secs) in table.items():
+            by = scan_bytes(kind, key)
+            rows.append(dict(kernel=f"scan_{kind}", shape=list(key[:5]), launches=n, total_ms=secs * 1e3,
+                             avg_us=secs / n * 1e6, algorithmic_MB=by / 1e6, GBs=by / (secs / n) / 1e9))
+        rows.sort(key=lambda r: -r["total_ms"])
+        scan_ms = sum(r["total_ms"] for r in rows)
+        roof = None
+        if rows:
+            d = rows[0]
+            roof = dict(bound="hbm", achieved=round(d["GBs"], 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=round(d["GBs"] / HBM_PEAK_GBS, 4), traffic=None, kernel=d["kernel"], shape=d["shape"],
+                        avg_launch_us=round(d["avg_us"], 1), launches=d["launches"],
+                        share_of_scan_time=round(d["total_ms"] / scan_ms, 3),
+                        scan_share_of_step=round(scan_ms / (elapsed * 1e3), 3))
+        if a.kernel_report:
+            os.makedirs(os.path.dirname(os.path.abspath(a.kernel_report)) or ".", exist_ok=True)
+            with open(a.kernel_report, "w") as f:
+                json.dump(dict(steps=a.steps, elapsed_s=elapsed, scan_ms_total=scan_ms, kernels=rows), f, indent=1)
+        cpu = None
+        if world == 1 and not a.no_cpu_baseline:
+            cpu = cpu_baseline(a.backbone, a.height, a.width, a.cpu_budget)
+        images = a.batch * world * a.steps
+        line = dict(metric=f"images/sec fwd+bwd {a.backbone} {a.height}x{a.width}", value=round(images / elapsed, 3),
+                    unit="images/s", n_gpus=world, steps=a.steps, warmup=a.warmup,
+                    ms_per_step=round(elapsed / a.steps * 1e3, 2), higher_is_better=True, scaling="weak",
+                    vs_baseline=None, dtype="f32", data="synthetic",
+                    config=dict(workload=f"{a.backbone} training step (fwd+bwd+AdamW), RGB-X pairs {a.height}x{a.width}, "
+                                         f"{a.classes} classes, fp32", per_gpu_batch=a.batch,
+                                global_batch=a.batch * world, parallelism=f"dp{world}",
+                                loss=round(float(loss.item()), 4)),
+                    roofline=roof, cpu_baseline=cpu)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

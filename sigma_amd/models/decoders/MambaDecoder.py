@@ -1,0 +1,146 @@
+"""Channel-aware Mamba decoder.
+
+Mirror of /root/reference/models/decoders/MambaDecoder.py (PatchExpand :12-30, UpsampleExpand
+:33-51, FinalUpsample_X4 :76-97, Mamba_up :101-148, MambaDecoder :151-280); only the
+deep_supervision=False path that models/builder.py:102 selects is built.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..encoders.vmamba import CVSSDecoderBlock
+
+
+def _up2(x_nhwc: torch.Tensor) -> torch.Tensor:
+    """bilinear x2 (align_corners=False) on an NHWC tensor."""
+    y = F.interpolate(x_nhwc.permute(0, 3, 1, 2), scale_factor=2, mode="bilinear", align_corners=False)
+    return y.permute(0, 2, 3, 1)
+
+
+class PatchExpand(nn.Module):
+    """Linear(C -> 2C), pixel-shuffle 2x2 ('b h w (p1 p2 c) -> b (h p1) (w p2) c'), LayerNorm(C/2)."""
+
+    def __init__(self, input_resolution, dim, dim_scale=2, norm_layer=nn.LayerNorm):
+        super().__init__()
+        self.input_resolution = input_resolution
+        self.dim = dim
+        self.expand = nn.Linear(dim, 2 * dim, bias=False) if dim_scale == 2 else nn.Identity()
+        self.norm = norm_layer(dim // dim_scale)
+
+    def forward(self, x):
+        x = self.expand(x)
+        B, H, W, C = x.shape
+        x = x.view(B, H, W, 2, 2, C // 4).permute(0, 1, 3, 2, 4, 5).reshape(B, 2 * H, 2 * W, C // 4)
+        return self.norm(x)
+
+
+class UpsampleExpand(nn.Module):
+    """Linear(C -> C/2), bilinear x2, LayerNorm(C/2)."""
+
+    def __init__(self, input_resolution, dim, patch_size=4, norm_layer=nn.LayerNorm):
+        super().__init__()
+        self.input_resolution = input_resolution
+        self.dim = dim
+        self.patch_size = patch_size
+        self.linear = nn.Linear(dim, dim // 2, bias=False)
+        self.output_dim = dim
+        self.norm = norm_layer(dim // 2)
+
+    def forward(self, x):
+        return self.norm(_up2(self.linear(x)))
+
+
+class FinalUpsample_X4(nn.Module):
+    """Linear, bilinear x2, Linear, bilinear x2, LayerNorm -- back to the input resolution."""
+
+    def __init__(self, input_resolution, dim, patch_size=4, norm_layer=nn.LayerNorm):
+        super().__init__()
+        self.input_resolution = input_resolution
+        self.dim = dim
+        self.patch_size = patch_size
+        self.linear1 = nn.Linear(dim, dim, bias=False)
+        self.linear2 = nn.Linear(dim, dim, bias=False)
+        self.output_dim = dim
+        self.norm = norm_layer(dim)
+
+    def forward(self, x):
+        x = _up2(self.linear1(x))
+        x = _up2(self.linear2(x))
+        return self.norm(x)
+
+
+class Mamba_up(nn.Module):
+    """`depth` CVSS blocks (d_state 4) followed by an optional UpsampleExpand."""
+
+    def __init__(self, dim, input_resolution, depth, dt_rank="auto", d_state=4, ssm_ratio=2.0, attn_drop_rate=0.0,
+                 drop_rate=0.0, mlp_ratio=4.0, drop_path=0.1, norm_layer=nn.LayerNorm, upsample=None,
+                 use_checkpoint=False, **kwargs):
+        super().__init__()
+        self.input_resolution = input_resolution
+        self.depth = depth
+        rates = drop_path if isinstance(drop_path, (list, tuple)) else [drop_path] * depth
+        self.blocks = nn.ModuleList([
+            CVSSDecoderBlock(hidden_dim=dim, drop_path=rates[i], norm_layer=norm_layer, attn_drop_rate=attn_drop_rate,
+                             d_state=d_state, dt_rank=dt_rank, ssm_ratio=ssm_ratio) for i in range(depth)])
+        self.upsample = (UpsampleExpand(input_resolution, dim=dim, patch_size=2, norm_layer=norm_layer)
+                         if upsample is not None else None)
+
+    def forward(self, x):
+        for blk in self.blocks:
+            x = blk(x)
+        return x if self.upsample is None else self.upsample(x)
+
+
+class MambaDecoder(nn.Module):
+    def __init__(self, img_size=(480, 640), in_channels=(96, 192, 384, 768), num_classes=40, dropout_ratio=0.1,
+                 embed_dim=96, align_corners=False, patch_size=4, depths=(4, 4, 4, 4), mlp_ratio=4.0, drop_rate=0.0,
+                 attn_drop_rate=0.0, drop_path_rate=0.1, norm_layer=nn.LayerNorm, use_checkpoint=False,
+                 deep_supervision=False, **kwargs):
+        super().__init__()
+        if deep_supervision:
+            raise NotImplementedError("models/builder.py:102 always builds MambaDecoder with deep_supervision=False")
+        depths = list(depths)
+        self.num_classes = num_classes
+        self.num_layers = len(depths)
+        self.mlp_ratio = mlp_ratio
+        self.patch_size = patch_size
+        self.patches_resolution = [img_size[0] // patch_size, img_size[1] // patch_size]
+        self.deep_supervision = False
+        dpr = [r.item() for r in torch.linspace(0, drop_path_rate, sum(depths))]
+        self.layers_up = nn.ModuleList()
+        for i in range(self.num_layers):
+            lvl = self.num_layers - 1 - i                         # encoder stage feeding this level
+            res = (self.patches_resolution[0] // 2 ** lvl, self.patches_resolution[1] // 2 ** lvl)
+            dim = int(embed_dim * 2 ** lvl)
+            if i == 0:
+                layer = PatchExpand(input_resolution=res, dim=dim, dim_scale=2, norm_layer=norm_layer)
+            else:
+                layer = Mamba_up(dim=dim, input_resolution=res, depth=depths[lvl], mlp_ratio=mlp_ratio,
+                                 drop=drop_rate, attn_drop=attn_drop_rate,
+                                 drop_path=dpr[sum(depths[:lvl]):sum(depths[:lvl + 1])], norm_layer=norm_layer,
+                                 upsample=PatchExpand if i < self.num_layers - 1 else None,
+                                 use_checkpoint=use_checkpoint)
+            self.layers_up.append(layer)
+        self.norm_up = norm_layer(embed_dim)
+        self.up = FinalUpsample_X4(input_resolution=tuple(self.patches_resolution), patch_size=4, dim=embed_dim)
+        self.output = nn.Conv2d(embed_dim, num_classes, kernel_size=1, bias=False)
+
+    def forward_up_features(self, inputs):
+        """inputs: 4 fused maps (B, C_i, H_i, W_i), finest first."""
+        y = self.layers_up[0](inputs[3].permute(0, 2, 3, 1))
+        for i in range(1, self.num_layers):
+            skip = inputs[3 - i]
+            H, W = skip.shape[2], skip.shape[3]
+            if y.shape[1] != H or y.shape[2] != W:               # odd sizes (PST900: 46 rows -> 45)
+                y = F.interpolate(y.permute(0, 3, 1, 2), size=(H, W), mode="bilinear", align_corners=False).permute(0, 2, 3, 1)
+            y = self.layers_up[i](y + skip.permute(0, 2, 3, 1))
+        return self.norm_up(y)
+
+    def up_x4(self, x, pz):
+        x = self.up(x)                                            # (B, 4H, 4W, C)
+        return self.output(x.permute(0, 3, 1, 2))
+
+    def forward(self, inputs):
+        return self.up_x4(self.forward_up_features(inputs), self.patch_size)

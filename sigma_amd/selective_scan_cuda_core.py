@@ -25,6 +25,21 @@ from . import _capi
 _DTYPES = {torch.float32: _capi.DTYPE_F32, torch.float16: _capi.DTYPE_F16, torch.bfloat16: _capi.DTYPE_BF16}
 
 
+_launch_hook = None
+
+
+def set_launch_hook(hook) -> None:
+    """Benchmark instrumentation: ``hook(kind, key, launch)`` must call ``launch()`` and may
+    bracket it with HIP events on the current stream.  ``key`` = (B, dim, L, N, G, elem_size).
+    ``None`` removes the hook.  Not used by the model code."""
+    global _launch_hook
+    _launch_hook = hook
+
+
+def _launch(kind, key, fn):
+    return fn() if _launch_hook is None else _launch_hook(kind, key, fn)
+
+
 def _check(cond: bool, msg: str) -> None:
     if not cond:
         raise RuntimeError(msg)
@@ -105,7 +120,9 @@ def fwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B: torch.Tensor, 
     _fill_fwd(fp, u, delta, A, B, C, D_, delta_bias_, out, x, delta_softplus, sizes)
     with torch.cuda.device(u.device):                               # CUDAGuard, :240
         stream = torch.cuda.current_stream(u.device).cuda_stream    # :241
-        _capi.check(lib.sigma_selective_scan_fwd(ctypes.byref(fp), ctypes.c_void_p(stream)), "selective_scan_fwd")
+        key = (batch, dim, seqlen, dstate, sizes[4], u.element_size())
+        _launch("fwd", key, lambda: _capi.check(
+            lib.sigma_selective_scan_fwd(ctypes.byref(fp), ctypes.c_void_p(stream)), "selective_scan_fwd"))
     return [out, x]
 
 
@@ -154,5 +171,7 @@ def bwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B: torch.Tensor, 
             bp.workspace, bp.workspace_bytes = _ptr(workspace), ws_bytes
         with torch.cuda.device(u.device):
             stream = torch.cuda.current_stream(u.device).cuda_stream
-            _capi.check(lib.sigma_selective_scan_bwd(ctypes.byref(bp), ctypes.c_void_p(stream)), "selective_scan_bwd")
+            key = (batch, dim, seqlen, dstate, n_groups, u.element_size())
+            _launch("bwd", key, lambda: _capi.check(
+                lib.sigma_selective_scan_bwd(ctypes.byref(bp), ctypes.c_void_p(stream)), "selective_scan_bwd"))
     return [du, ddelta, dA, dB.to(B.dtype), dC.to(C.dtype), dD, ddelta_bias]   # :360

@@ -1,0 +1,62 @@
+"""GPU parity of the full model path (HIP scans inside sigma_amd.models) -- run with -m gpu.
+
+Checkers: the golden fixtures produced by the REFERENCE's own Python model and, at the real
+480x640 size (BASELINE.json configs[0]/[1]), the CPU oracle model.  Tolerance for logits is the
+north star's 1e-3 relative (to the logit scale)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.model_utils import assert_logits_close, build_model, digest, fill, load_model_golden, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("case", ["tiny_64x96", "tiny_72x88_b2"])
+def test_logits_loss_and_grads_match_reference_fixtures(case):
+    meta, z = load_model_golden(case)
+    model = build_model(meta["backbone"], meta["num_classes"], meta["H"], meta["W"]).cuda().eval()
+    rgb, x, label = fill.make_inputs(meta["batch"], meta["H"], meta["W"], meta["num_classes"])
+    with torch.no_grad():
+        logits = model(rgb.cuda(), x.cuda())
+    assert_logits_close(logits, torch.from_numpy(z["logits"]), 1e-3)
+    loss = model(rgb.cuda(), x.cuda(), label.cuda())
+    assert abs(loss.item() - float(z["loss"])) < 1e-3
+    loss.backward()
+    names, ref = list(z["grad_names"]), z["grad_digest"]
+    got = dict(model.named_parameters())
+    bad = []
+    for n, r in zip(names, ref):
+        g = got[n].grad
+        assert g is not None, n
+        d = digest(g)
+        tol = 5e-3 * (abs(r[1]) + 1e-6)              # relative to the L1 mass of the gradient
+        if not (abs(d[0] - r[0]) < tol and abs(d[1] - r[1]) < tol and abs(d[2] - r[2]) < tol):
+            bad.append((n, d.tolist(), r.tolist()))
+    assert not bad, bad[:5]
+
+
+def test_sigma_tiny_480x640_logits_vs_cpu_oracle():
+    """BASELINE.json configs[1]: sigma_tiny, MFNet shape 480x640, HIP path vs CPU reference path."""
+    from oracle import sigma_oracle
+    model = build_model("sigma_tiny", 9, 480, 640).cuda().eval()
+    rgb, x, _ = fill.make_inputs(1, 480, 640, 9, seed=3)
+    with torch.no_grad():
+        logits = model(rgb.cuda(), x.cuda())
+    ref = sigma_oracle.sigma_forward(model.state_dict(), rgb, x, "sigma_tiny")
+    assert_logits_close(logits, ref, 1e-3)
+
+
+def test_train_mode_step_and_determinism_of_forward():
+    model = build_model("sigma_tiny", 9, 96, 128).cuda()
+    rgb, x, label = fill.make_inputs(2, 96, 128, 9, seed=5)
+    model.eval()
+    with torch.no_grad():
+        a = model(rgb.cuda(), x.cuda())
+        b = model(rgb.cuda(), x.cuda())
+    assert torch.equal(a, b)
+    model.train()                                     # DropPath active: still finite, all params get grads
+    loss = model(rgb.cuda(), x.cuda(), label.cuda())
+    loss.backward()
+    assert torch.isfinite(loss)
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())

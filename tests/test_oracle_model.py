@@ -1,0 +1,81 @@
+"""Pin the CPU model oracle (oracle/sigma_oracle.py) and sigma_amd's host-side model logic to
+fixtures produced by the REFERENCE's own Python model (tests/golden/make_golden_model.py)."""
+import numpy as np
+import pytest
+import torch
+
+from tests.model_utils import assert_logits_close, build_model, digest, fill, load_model_golden, rel_err
+from tests.oracle_backend import use_oracle_scan
+
+CASES = ["tiny_64x96", "tiny_72x88_b2"]
+
+
+@pytest.fixture(scope="module")
+def tiny_model():
+    return build_model("sigma_tiny", num_classes=9, H=64, W=96).eval()
+
+
+def test_state_dict_contract_matches_reference(tiny_model):
+    """Strict key/shape equality with the reference model (utils/pyt_utils.py:180 loads strict)."""
+    meta, z = load_model_golden("tiny_64x96")
+    keys = sorted(tiny_model.state_dict().keys())
+    assert keys == list(z["keys"])
+    assert sum(p.numel() for p in tiny_model.parameters()) == int(z["n_params"])
+
+
+@pytest.mark.parametrize("backbone,expected", [("sigma_tiny", 48.29), ("sigma_small", 69.81), ("sigma_base", 121.41)])
+def test_parameter_counts(backbone, expected):
+    """48.29 / 69.81 / 121.41 M parameters (figs/overall_flops.png)."""
+    from tests.model_utils import cfg_for
+    from sigma_amd.models.builder import EncoderDecoder
+    m = EncoderDecoder(cfg_for(backbone, 9), criterion=None)
+    assert round(sum(p.numel() for p in m.parameters()) / 1e6, 2) == expected
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_oracle_model_matches_reference_logits(case):
+    from oracle import sigma_oracle
+    meta, z = load_model_golden(case)
+    model = build_model(meta["backbone"], meta["num_classes"], meta["H"], meta["W"])
+    rgb, x, label = fill.make_inputs(meta["batch"], meta["H"], meta["W"], meta["num_classes"])
+    logits, feats = sigma_oracle.sigma_forward(model.state_dict(), rgb, x, meta["backbone"], return_features=True)
+    ref = torch.from_numpy(z["logits"])
+    assert_logits_close(logits, ref, 2e-5)
+    for i, f in enumerate(feats):
+        g = z[f"feat{i}"]
+        if g.shape == (3,):
+            np.testing.assert_allclose(digest(f), g, rtol=2e-4, atol=1e-3)
+        else:
+            assert rel_err(f, torch.from_numpy(g)) < 2e-5
+    loss = sigma_oracle.sigma_loss(model.state_dict(), rgb, x, label, meta["backbone"])
+    assert abs(loss.item() - float(z["loss"])) < 1e-4
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_host_model_logic_matches_reference(case):
+    """sigma_amd's nn.Module graph (merged projections, batched Siamese pass, view-based
+    cross scan/merge) computes the reference's function: logits, loss and EVERY parameter
+    gradient.  The scan is the CPU oracle here (injected by the test); the HIP scan is checked
+    against the same fixtures in tests/test_model_gpu.py."""
+    meta, z = load_model_golden(case)
+    model = build_model(meta["backbone"], meta["num_classes"], meta["H"], meta["W"]).eval()
+    rgb, x, label = fill.make_inputs(meta["batch"], meta["H"], meta["W"], meta["num_classes"])
+    with use_oracle_scan():
+        with torch.no_grad():
+            logits = model(rgb, x)
+        assert_logits_close(logits, torch.from_numpy(z["logits"]), 2e-5)
+        loss = model(rgb, x, label)
+        assert abs(loss.item() - float(z["loss"])) < 1e-4
+        loss.backward()
+    names = list(z["grad_names"])
+    ref = z["grad_digest"]
+    got = dict(model.named_parameters())
+    assert sorted(names) == sorted(got.keys())
+    bad = []
+    for n, r in zip(names, ref):
+        g = got[n].grad
+        assert g is not None, f"{n} received no gradient (DDP find_unused_parameters=False would hang)"
+        d = digest(g)
+        if not np.allclose(d, r, rtol=2e-3, atol=2e-3 * (abs(r[1]) / max(g.numel(), 1) + 1e-6) * g.numel() ** 0.5 + 1e-6):
+            bad.append((n, d, r))
+    assert not bad, bad[:5]
