@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SIGMA_SCAN_ABI_VERSION 2
+#define SIGMA_SCAN_ABI_VERSION 3
 
 /* dtype of u, delta, B, C, out, dout, du, ddelta  (input_t of the reference,
  * selective_scan.cpp:174: float / half / bfloat16).  A, D, delta_bias, x, dA,
@@ -55,9 +55,16 @@ enum sigma_status {
     SIGMA_ERR_BAD_OPTION = 7
 };
 
-/* The chunk length of the checkpoint tensor x: n_chunks = ceil(seqlen / 2048)
- * (selective_scan.cpp:225). */
+/* The SHAPE of the checkpoint tensor x follows the reference: (batch, dim, n_chunks, 2*dstate)
+ * float32 with n_chunks = ceil(seqlen / 2048) (selective_scan.cpp:225-228).  Its CONTENTS are
+ * private scratch between this library's fwd and bwd (the reference never documents or tests
+ * them; its own bwd only accepts the x of its own fwd).  Layout used here -- the kernels tile the
+ * sequence by 1280 / 640 / 320 / 256 elements, which 2048 is not a multiple of:
+ *     checkpoint j = the N states of a row after element min(seqlen, (j+1)*1280) - 1,
+ *     for j < ceil(seqlen / 1280), stored at x[b, r, j / 2, 2*n + (j % 2)].
+ * 2 * ceil(seqlen/2048) >= ceil(seqlen/1280), so it always fits.  Unused slots are not written. */
 #define SIGMA_SCAN_CHUNK 2048
+#define SIGMA_SCAN_CKPT_PITCH 1280
 /* dstate limit of the reference (selective_scan.cpp:10,201). */
 #define SIGMA_SCAN_MAX_DSTATE 256
 
@@ -71,6 +78,15 @@ typedef struct sigma_scan_fwd_params {
     int32_t n_chunks;   /* ceil(L / 2048); checked */
     int32_t io_dtype;   /* enum sigma_dtype */
     int32_t delta_softplus;
+    /* Extensions for the fused SS2D caller (both 0 = the reference operator):
+     *  n_rev_groups: the LAST n_rev_groups groups scan the sequence backwards -- every
+     *      sequence operand of their rows (u, delta, B, C, out, dout, du, ddelta, dB, dC) is
+     *      read / written at index seqlen-1-l.  This is CrossScan's flip (vmamba.py:80-98,
+     *      directions 2 and 3) done by addressing instead of by materialised copies.
+     *  u_row_mod: when > 0, channel row r reads u row (r % u_row_mod): the four CrossScan
+     *      directions share two physical copies of x (row-major, column-major). */
+    int32_t n_rev_groups;
+    int32_t u_row_mod;
     /* inputs */
     const void *u;            /* (B, dim, L)        io_dtype */
     const void *delta;        /* (B, dim, L)        io_dtype */
@@ -81,8 +97,8 @@ typedef struct sigma_scan_fwd_params {
     const float *delta_bias;  /* (dim) or NULL      f32      */
     /* outputs */
     void *out;                /* (B, dim, L)        io_dtype */
-    float *x;                 /* (B, dim, n_chunks, 2N) f32 contiguous, or NULL:
-                                 float2[n] = (prod_{l<=end(c)} a[n,l], x[n,end(c)]) */
+    float *x;                 /* (B, dim, n_chunks, 2N) f32 contiguous, or NULL (inference):
+                                 state checkpoints every 1280 elements, layout above */
     /* element strides */
     int64_t u_batch_stride, u_d_stride;
     int64_t delta_batch_stride, delta_d_stride;
@@ -93,8 +109,9 @@ typedef struct sigma_scan_fwd_params {
 } sigma_scan_fwd_params;
 
 typedef struct sigma_scan_bwd_params {
-    sigma_scan_fwd_params fwd;   /* out is unused; x is the tensor saved by fwd
-                                    (may be NULL only when n_chunks == 1, selective_scan.cpp:320) */
+    sigma_scan_fwd_params fwd;   /* out is unused; x is the tensor saved by fwd (the reference
+                                    requires it when n_chunks > 1, selective_scan.cpp:320; here it
+                                    may be NULL only when seqlen <= SIGMA_SCAN_CKPT_PITCH) */
     const void *dout;            /* (B, dim, L)   io_dtype */
     void *du;                    /* (B, dim, L)   io_dtype, fully written */
     void *ddelta;                /* (B, dim, L)   io_dtype, fully written */
@@ -135,18 +152,19 @@ const char *sigma_scan_last_error(void);
 int sigma_scan_abi_version(void);
 
 /* Tuning knobs for benchmarking; 0 restores the built-in heuristic.
- *   "fwd_items"  items per lane in the forward kernel  (4, 8 or 16)
- *   "fwd_waves"  rows (= waves) per workgroup, forward  (1,2,4,8,16)
- *   "bwd_items"  items per lane in the backward kernel (4 or 8)
- *   "bwd_waves"  rows per workgroup, backward
+ *   "fwd_items" / "bwd_items"  elements per lane: fwd {4,5,10,20}, bwd {4,5,10} (tile = 64 x items)
+ *   "fwd_waves" / "bwd_waves"  channel rows per workgroup (1..16; must divide dim / n_groups)
+ *   "fwd_tiles"                consecutive sequence tiles per workgroup, forward (rows x tiles <= 16)
+ *   "fwd_nb" / "bwd_nb"        states per B/C staging block {1,2,4,8}
+ *   "no_glds"                  1 = stage B/C through registers instead of global_load_lds
  * Returns SIGMA_ERR_BAD_OPTION for unknown names / unsupported values. */
 int sigma_scan_set_option(const char *name, int value);
 int sigma_scan_get_option(const char *name);
 
-/* Launch geometry the heuristic would pick for a problem (for reports/tests):
- * writes {items_per_lane, waves_per_workgroup, workgroups, lds_bytes} */
-int sigma_scan_fwd_plan(const sigma_scan_fwd_params *params, int32_t plan[4]);
-int sigma_scan_bwd_plan(const sigma_scan_bwd_params *params, int32_t plan[4]);
+/* Launch geometry the heuristic picks for a problem (for reports/tests): writes
+ * {items_per_lane, rows_per_workgroup, workgroups, lds_bytes, tiles_per_workgroup, states_per_block} */
+int sigma_scan_fwd_plan(const sigma_scan_fwd_params *params, int32_t plan[6]);
+int sigma_scan_bwd_plan(const sigma_scan_bwd_params *params, int32_t plan[6]);
 
 /* On-device self test of the wave64 DPP scan primitives against a serial loop.
  * Returns 0 when every lane matches; enqueues on `stream` and synchronises it. */

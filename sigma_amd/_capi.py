@@ -14,8 +14,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SIGMA_HIP_LIB lets a benchmark A/B an experimental build of the same ABI; default is the in-tree library
 LIB_PATH = os.environ.get("SIGMA_HIP_LIB") or os.path.join(_HERE, "lib", "libsigma_hip.so")
 
-SIGMA_SCAN_ABI_VERSION = 2
+SIGMA_SCAN_ABI_VERSION = 3
 SIGMA_SCAN_CHUNK = 2048
+SIGMA_SCAN_CKPT_PITCH = 1280
 SIGMA_SCAN_MAX_DSTATE = 256
 
 DTYPE_F32, DTYPE_F16, DTYPE_BF16 = 0, 1, 2
@@ -30,6 +31,7 @@ class FwdParams(ctypes.Structure):
         ("batch", ctypes.c_int32), ("dim", ctypes.c_int32), ("seqlen", ctypes.c_int32),
         ("dstate", ctypes.c_int32), ("n_groups", ctypes.c_int32), ("n_chunks", ctypes.c_int32),
         ("io_dtype", ctypes.c_int32), ("delta_softplus", ctypes.c_int32),
+        ("n_rev_groups", ctypes.c_int32), ("u_row_mod", ctypes.c_int32),
         ("u", ctypes.c_void_p), ("delta", ctypes.c_void_p), ("A", ctypes.c_void_p),
         ("B", ctypes.c_void_p), ("C", ctypes.c_void_p), ("D", ctypes.c_void_p),
         ("delta_bias", ctypes.c_void_p),
@@ -104,9 +106,9 @@ def load() -> ctypes.CDLL:
     lib.sigma_scan_set_option.restype = ctypes.c_int
     lib.sigma_scan_get_option.argtypes = [ctypes.c_char_p]
     lib.sigma_scan_get_option.restype = ctypes.c_int
-    lib.sigma_scan_fwd_plan.argtypes = [P(FwdParams), P(ctypes.c_int32 * 4)]
+    lib.sigma_scan_fwd_plan.argtypes = [P(FwdParams), P(ctypes.c_int32 * 6)]
     lib.sigma_scan_fwd_plan.restype = ctypes.c_int
-    lib.sigma_scan_bwd_plan.argtypes = [P(BwdParams), P(ctypes.c_int32 * 4)]
+    lib.sigma_scan_bwd_plan.argtypes = [P(BwdParams), P(ctypes.c_int32 * 6)]
     lib.sigma_scan_bwd_plan.restype = ctypes.c_int
     lib.sigma_scan_selftest.argtypes = [ctypes.c_void_p]
     lib.sigma_scan_selftest.restype = ctypes.c_int

@@ -18,7 +18,8 @@ namespace {
 
 thread_local std::string g_err;
 
-std::atomic<int> g_opt_fwd_items{0}, g_opt_fwd_waves{0}, g_opt_bwd_items{0}, g_opt_bwd_waves{0};
+std::atomic<int> g_opt_fwd_items{0}, g_opt_fwd_waves{0}, g_opt_fwd_tiles{0}, g_opt_fwd_nb{0};
+std::atomic<int> g_opt_bwd_items{0}, g_opt_bwd_waves{0}, g_opt_bwd_nb{0}, g_opt_no_glds{0};
 
 int fail(int code, const char* fmt, ...) {
     char buf[512];
@@ -49,6 +50,10 @@ int check_fwd(const sigma_scan_fwd_params* p, bool need_out, bool need_ptrs = tr
     if (p->n_chunks != (p->seqlen + SIGMA_SCAN_CHUNK - 1) / SIGMA_SCAN_CHUNK)
         return fail(SIGMA_ERR_BAD_SHAPE, "n_chunks must be ceil(seqlen/2048) (got %d for seqlen %d)", p->n_chunks,
                     p->seqlen);
+    if (p->n_rev_groups < 0 || p->n_rev_groups > p->n_groups)
+        return fail(SIGMA_ERR_BAD_SHAPE, "n_rev_groups must be in [0, n_groups] (got %d)", p->n_rev_groups);
+    if (p->u_row_mod < 0 || p->u_row_mod > p->dim)
+        return fail(SIGMA_ERR_BAD_SHAPE, "u_row_mod must be in [0, dim] (got %d)", p->u_row_mod);
     if (p->batch == 0 || p->seqlen == 0 || !need_ptrs) return SIGMA_OK;
     if (!p->u || !p->delta || !p->A || !p->B || !p->C || (need_out && !p->out))
         return fail(SIGMA_ERR_NULL_ARG, "u/delta/A/B/C/out must be non-NULL device pointers");
@@ -67,14 +72,17 @@ bool vec_ok_fwd(const sigma_scan_fwd_params* p, bool with_out) {
     return ok;
 }
 
-sigma::FwdArgs make_fwd_args(const sigma_scan_fwd_params* p, int nwaves, bool vec) {
+sigma::FwdArgs make_fwd_args(const sigma_scan_fwd_params* p, int R, int W, int NB, bool vec) {
     sigma::FwdArgs a;
     std::memset(&a, 0, sizeof(a));
     a.u = p->u; a.delta = p->delta; a.A = p->A; a.B = p->B; a.C = p->C; a.D = p->D; a.bias = p->delta_bias;
     a.out = p->out; a.x = p->x;
     a.batch = p->batch; a.dim = p->dim; a.L = p->seqlen; a.N = p->dstate; a.G = p->n_groups;
     a.n_chunks = p->n_chunks; a.rows_per_group = p->dim / p->n_groups; a.softplus = p->delta_softplus ? 1 : 0;
-    a.vec_ok = vec ? 1 : 0; a.rowblocks = p->dim / nwaves;
+    a.vec_ok = vec ? 1 : 0; a.rowblocks = p->dim / R;
+    a.R = R; a.W = W; a.NB = NB;
+    a.rev_from_group = p->n_groups - p->n_rev_groups;
+    a.u_row_mod = p->u_row_mod;
     a.u_bs = p->u_batch_stride; a.u_ds = p->u_d_stride; a.dt_bs = p->delta_batch_stride; a.dt_ds = p->delta_d_stride;
     a.A_ds = p->A_d_stride; a.A_ns = p->A_dstate_stride;
     a.B_bs = p->B_batch_stride; a.B_gs = p->B_group_stride; a.B_ns = p->B_dstate_stride;
@@ -83,55 +91,117 @@ sigma::FwdArgs make_fwd_args(const sigma_scan_fwd_params* p, int nwaves, bool ve
     return a;
 }
 
-// rows (waves) per workgroup: the largest power of two <= cap that divides the rows of a
-// group (all rows of a workgroup must share B/C), shrunk while the grid would leave CUs idle.
-int pick_waves(int rows_per_group, long total_rows, int cap, int forced) {
-    if (forced > 0) {
-        int w = forced;
-        while (w > 1 && rows_per_group % w != 0) w >>= 1;
-        return w;
+// ---------------------------------------------------------------- launch planning
+// Work per element-state in VALU issue slots (fold + replay + one wave scan per T elements):
+// used only to rank tile lengths against the padding they cause.
+double fwd_cost_per_element(int T) { return 7.0 + 24.0 / T; }
+double bwd_cost_per_element(int T) { return 18.0 + 48.0 / T; }
+
+int pick_items(int L, const int* cand, int ncand, double (*cost)(int), int forced) {
+    for (int i = 0; i < ncand; ++i) if (forced == cand[i]) return forced;
+    int best = cand[0];
+    double best_score = 1e300;
+    for (int i = 0; i < ncand; ++i) {
+        const int T = cand[i];
+        const long tile = 64L * T;
+        const long padded = (L + tile - 1) / tile * tile;
+        const double score = (double)padded * cost(T);
+        if (score < best_score) { best_score = score; best = T; }
     }
-    int w = cap;
-    while (w > 1 && rows_per_group % w != 0) w >>= 1;
-    // keep >= 2 workgroups per CU in flight when the problem allows it (256 CUs)
-    while (w > 4 && total_rows / w < 512) w >>= 1;
-    return w;
+    return best;
 }
 
-int pick_items_fwd(int L, int N, int forced) {
-    if (forced == 4 || forced == 8 || forced == 16) return forced;
-    if (L <= 256) return 4;
-    if (L <= 768) return 8;
-    (void)N;
-    return 16;
+constexpr int kCUs = 256;
+constexpr size_t kLdsLimit = 160 * 1024;
+
+struct Plan { int items, rows, tiles, nb, grid; bool glds; size_t lds; };
+
+// global_load_lds staging: f32, 16-byte aligned rows, whole chunks in range, 31-bit offsets inside
+// one (batch, group) slice; the per-wave chunk plan holds kStageMaxIt units (scan_device.h).
+bool glds_ok(const sigma_scan_fwd_params* p, bool vec) {
+    const int64_t span = (int64_t)p->dstate * (p->B_dstate_stride > p->C_dstate_stride ? p->B_dstate_stride : p->C_dstate_stride) + p->seqlen;
+    return vec && p->io_dtype == SIGMA_DTYPE_F32 && (p->seqlen % 4) == 0 && g_opt_no_glds.load() == 0 &&
+           p->B_dstate_stride >= 0 && p->C_dstate_stride >= 0 && span * 4 < (int64_t(1) << 31);
+}
+bool glds_fits(int T, int NB, int W, int nwaves) {
+    const int units = (NB * W * 16 * T + 63) / 64;
+    return units <= sigma::kStageMaxIt * nwaves;
 }
 
-int pick_items_bwd(int L, int forced) {
-    if (forced == 4 || forced == 8) return forced;
-    return L <= 256 ? 4 : 8;
-}
-
-struct Plan { int items, waves, grid; size_t lds; };
-
-Plan plan_fwd(const sigma_scan_fwd_params* p) {
+// Forward: rows R x tiles W per workgroup (R*W <= 16 waves, R divides the rows of a group).
+// cost ~ (rounds of workgroups over the 256 CUs) x (super-tiles each walks) x (work per
+// super-tile step, which grows with the B/C restaging share 1/R and the extra barrier of W > 1).
+Plan plan_fwd(const sigma_scan_fwd_params* p, bool vec) {
+    // T = 20 (one 1280 tile) exists but needs ~150 VGPRs -> 12-wave workgroups; it is only used
+    // when forced ("fwd_items" = 20) until it measures faster than two 640 tiles.
+    static const int cand[] = {10, 5, 4};
     Plan pl;
-    pl.items = pick_items_fwd(p->seqlen, p->dstate, g_opt_fwd_items.load());
-    pl.waves = pick_waves(p->dim / p->n_groups, (long)p->batch * p->dim, 16, g_opt_fwd_waves.load());
-    pl.grid = (p->dim / pl.waves) * p->batch;
-    pl.lds = sigma::fwd_lds_bytes(pl.items, pl.waves, p->dstate);
+    const int forced_items = g_opt_fwd_items.load();
+    pl.items = forced_items == 20 ? 20 : pick_items(p->seqlen, cand, 3, fwd_cost_per_element, forced_items);
+    pl.glds = glds_ok(p, vec);
+    const int rpg = p->dim / p->n_groups;
+    const long total_rows = (long)p->batch * p->dim;
+    const int tile = 64 * pl.items;
+    const int ntiles = (p->seqlen + tile - 1) / tile;
+    const int fr = g_opt_fwd_waves.load(), fw = g_opt_fwd_tiles.load(), fnb = g_opt_fwd_nb.load();
+    double best = 1e300;
+    pl.rows = 1; pl.tiles = 1; pl.nb = 1;
+    const int maxw = pl.items >= 20 ? 12 : 16;                  // scan_fwd.hip: fwd_max_waves<T>
+    for (int R = maxw; R >= 1; --R) {
+        if (rpg % R != 0) continue;
+        if (fr > 0 && R != fr && rpg % fr == 0 && fr <= maxw) continue;   // forced rows (when legal)
+        int Wmax = maxw / R;
+        if (Wmax > ntiles) Wmax = ntiles;
+        if (Wmax < 1) Wmax = 1;
+        for (int W = Wmax; W >= 1; --W) {
+            if (fw > 0 && W != (fw < Wmax ? fw : Wmax)) continue;
+            int NB = W == 1 ? 4 : (W == 2 ? 2 : 1);
+            if (fnb > 0) NB = fnb;
+            if (NB > p->dstate) NB = p->dstate;
+            while (NB > 1 && sigma::fwd_lds_bytes(pl.items, R, W, NB, p->dstate) > kLdsLimit) NB >>= 1;
+            if (sigma::fwd_lds_bytes(pl.items, R, W, NB, p->dstate) > kLdsLimit) continue;
+            const long nwg = total_rows / R;
+            const long rounds = (nwg + kCUs - 1) / kCUs;
+            const int nsuper = (ntiles + W - 1) / W;
+            const double waves = (double)R * W;
+            // a CU with few waves runs each of them faster, but not proportionally
+            const double per_step = (0.35 + 0.65 * waves / maxw) * (1.0 + 2.0 / R + (W > 1 ? 0.15 : 0.0));
+            const double cost = (double)rounds * nsuper * per_step;
+            if (cost < best) { best = cost; pl.rows = R; pl.tiles = W; pl.nb = NB; }
+        }
+    }
+    pl.grid = (int)(total_rows / pl.rows);
+    pl.lds = sigma::fwd_lds_bytes(pl.items, pl.rows, pl.tiles, pl.nb, p->dstate);
+    pl.glds = pl.glds && glds_fits(pl.items, pl.nb, pl.tiles, pl.rows * pl.tiles);
     return pl;
 }
 
-Plan plan_bwd(const sigma_scan_fwd_params* p) {
+Plan plan_bwd(const sigma_scan_fwd_params* p, bool vec) {
+    static const int cand[] = {10, 5, 4};
     Plan pl;
-    pl.items = pick_items_bwd(p->seqlen, g_opt_bwd_items.load());
-    pl.waves = pick_waves(p->dim / p->n_groups, (long)p->batch * p->dim, 16, g_opt_bwd_waves.load());
-    pl.lds = sigma::bwd_lds_bytes(pl.items, pl.waves, p->dstate);
-    while (pl.lds > 160 * 1024 && pl.waves > 1) {   // very large dstate: fewer rows per workgroup
-        pl.waves >>= 1;
-        pl.lds = sigma::bwd_lds_bytes(pl.items, pl.waves, p->dstate);
+    pl.items = pick_items(p->seqlen, cand, 3, bwd_cost_per_element, g_opt_bwd_items.load());
+    pl.glds = glds_ok(p, vec);
+    pl.tiles = 1;
+    const int rpg = p->dim / p->n_groups;
+    const long total_rows = (long)p->batch * p->dim;
+    const int fr = g_opt_bwd_waves.load();
+    int NB = g_opt_bwd_nb.load() > 0 ? g_opt_bwd_nb.load() : 4;
+    if (NB > p->dstate) NB = p->dstate;
+    double best = 1e300;
+    pl.rows = 1; pl.nb = NB;
+    const int maxw = pl.items >= 10 ? 12 : 16;                        // scan_bwd.hip: bwd_max_waves<T>
+    for (int R = maxw; R >= 1; --R) {
+        if (rpg % R != 0) continue;
+        if (fr > 0 && R != fr && rpg % fr == 0 && fr <= maxw) continue;   // forced rows (when legal)
+        if (sigma::bwd_lds_bytes(pl.items, R, NB, p->dstate) > kLdsLimit) continue;
+        const long nwg = total_rows / R;
+        const long rounds = (nwg + kCUs - 1) / kCUs;
+        const double cost = (double)rounds * (0.35 + 0.65 * R / maxw) * (1.0 + 0.5 / R);
+        if (cost < best) { best = cost; pl.rows = R; }
     }
-    pl.grid = (p->dim / pl.waves) * p->batch;
+    pl.grid = (int)(total_rows / pl.rows);
+    pl.lds = sigma::bwd_lds_bytes(pl.items, pl.rows, pl.nb, p->dstate);
+    pl.glds = pl.glds && glds_fits(pl.items, pl.nb, 1, pl.rows);
     return pl;
 }
 
@@ -143,53 +213,56 @@ int sigma_scan_abi_version(void) { return SIGMA_SCAN_ABI_VERSION; }
 
 const char* sigma_scan_last_error(void) { return g_err.c_str(); }
 
+namespace {
+struct OptDesc { const char* name; std::atomic<int>* var; int allowed[8]; };
+OptDesc g_opts[] = {
+    {"fwd_items", &g_opt_fwd_items, {0, 4, 5, 10, 20, -1}},
+    {"bwd_items", &g_opt_bwd_items, {0, 4, 5, 10, -1}},
+    {"fwd_waves", &g_opt_fwd_waves, {-2}},     // rows per workgroup, 0..16
+    {"bwd_waves", &g_opt_bwd_waves, {-2}},
+    {"fwd_tiles", &g_opt_fwd_tiles, {-2}},     // sequence tiles per workgroup, 0..16
+    {"fwd_nb", &g_opt_fwd_nb, {0, 1, 2, 4, 8, -1}},
+    {"bwd_nb", &g_opt_bwd_nb, {0, 1, 2, 4, 8, -1}},
+    {"no_glds", &g_opt_no_glds, {0, 1, -1}},
+};
+}  // namespace
+
 int sigma_scan_set_option(const char* name, int value) {
     if (!name) return fail(SIGMA_ERR_NULL_ARG, "option name is NULL");
-    auto pow2 = [](int v) { return v == 0 || v == 1 || v == 2 || v == 4 || v == 8 || v == 16; };
-    if (!std::strcmp(name, "fwd_items")) {
-        if (!(value == 0 || value == 4 || value == 8 || value == 16)) return fail(SIGMA_ERR_BAD_OPTION, "fwd_items in {0,4,8,16}");
-        g_opt_fwd_items = value; return SIGMA_OK;
-    }
-    if (!std::strcmp(name, "bwd_items")) {
-        if (!(value == 0 || value == 4 || value == 8)) return fail(SIGMA_ERR_BAD_OPTION, "bwd_items in {0,4,8}");
-        g_opt_bwd_items = value; return SIGMA_OK;
-    }
-    if (!std::strcmp(name, "fwd_waves")) {
-        if (!pow2(value)) return fail(SIGMA_ERR_BAD_OPTION, "fwd_waves in {0,1,2,4,8,16}");
-        g_opt_fwd_waves = value; return SIGMA_OK;
-    }
-    if (!std::strcmp(name, "bwd_waves")) {
-        if (!pow2(value)) return fail(SIGMA_ERR_BAD_OPTION, "bwd_waves in {0,1,2,4,8,16}");
-        g_opt_bwd_waves = value; return SIGMA_OK;
+    for (auto& o : g_opts) {
+        if (std::strcmp(name, o.name)) continue;
+        bool ok = false;
+        if (o.allowed[0] == -2) ok = value >= 0 && value <= 16;
+        else for (int i = 0; i < 8 && o.allowed[i] != -1; ++i) ok = ok || o.allowed[i] == value;
+        if (!ok) return fail(SIGMA_ERR_BAD_OPTION, "value %d not allowed for option '%s'", value, name);
+        *o.var = value;
+        return SIGMA_OK;
     }
     return fail(SIGMA_ERR_BAD_OPTION, "unknown option '%s'", name);
 }
 
 int sigma_scan_get_option(const char* name) {
     if (!name) return -1;
-    if (!std::strcmp(name, "fwd_items")) return g_opt_fwd_items.load();
-    if (!std::strcmp(name, "bwd_items")) return g_opt_bwd_items.load();
-    if (!std::strcmp(name, "fwd_waves")) return g_opt_fwd_waves.load();
-    if (!std::strcmp(name, "bwd_waves")) return g_opt_bwd_waves.load();
+    for (auto& o : g_opts) if (!std::strcmp(name, o.name)) return o.var->load();
     return -1;
 }
 
-int sigma_scan_fwd_plan(const sigma_scan_fwd_params* p, int32_t plan[4]) {
+int sigma_scan_fwd_plan(const sigma_scan_fwd_params* p, int32_t plan[6]) {
     int rc = check_fwd(p, false, false);
     if (rc) return rc;
     if (!plan) return fail(SIGMA_ERR_NULL_ARG, "plan is NULL");
-    Plan pl = plan_fwd(p);
-    plan[0] = pl.items; plan[1] = pl.waves; plan[2] = pl.grid; plan[3] = (int32_t)pl.lds;
+    Plan pl = plan_fwd(p, true);
+    plan[0] = pl.items; plan[1] = pl.rows; plan[2] = pl.grid; plan[3] = (int32_t)pl.lds; plan[4] = pl.tiles; plan[5] = pl.nb;
     return SIGMA_OK;
 }
 
-int sigma_scan_bwd_plan(const sigma_scan_bwd_params* p, int32_t plan[4]) {
+int sigma_scan_bwd_plan(const sigma_scan_bwd_params* p, int32_t plan[6]) {
     if (!p) return fail(SIGMA_ERR_NULL_ARG, "params is NULL");
     int rc = check_fwd(&p->fwd, false, false);
     if (rc) return rc;
     if (!plan) return fail(SIGMA_ERR_NULL_ARG, "plan is NULL");
-    Plan pl = plan_bwd(&p->fwd);
-    plan[0] = pl.items; plan[1] = pl.waves; plan[2] = pl.grid; plan[3] = (int32_t)pl.lds;
+    Plan pl = plan_bwd(&p->fwd, true);
+    plan[0] = pl.items; plan[1] = pl.rows; plan[2] = pl.grid; plan[3] = (int32_t)pl.lds; plan[4] = pl.tiles; plan[5] = pl.nb;
     return SIGMA_OK;
 }
 
@@ -197,21 +270,33 @@ int sigma_selective_scan_fwd(const sigma_scan_fwd_params* p, void* stream) {
     int rc = check_fwd(p, true);
     if (rc) return rc;
     if (p->batch == 0 || p->seqlen == 0) return SIGMA_OK;
-    const Plan pl = plan_fwd(p);
-    if (pl.lds > 160 * 1024) return fail(SIGMA_ERR_BAD_SHAPE, "LDS budget exceeded (%zu B)", pl.lds);
-    const sigma::FwdArgs a = make_fwd_args(p, pl.waves, vec_ok_fwd(p, true));
-    hipError_t e = sigma::launch_scan_fwd(a, p->io_dtype, pl.items, pl.waves, static_cast<hipStream_t>(stream));
+    const bool vec = vec_ok_fwd(p, true) && (p->n_rev_groups == 0 || p->seqlen % 4 == 0);
+    const Plan pl = plan_fwd(p, vec);
+    if (pl.lds > kLdsLimit) return fail(SIGMA_ERR_BAD_SHAPE, "LDS budget exceeded (%zu B)", pl.lds);
+    const sigma::FwdArgs a = make_fwd_args(p, pl.rows, pl.tiles, pl.nb, vec);
+    hipError_t e = sigma::launch_scan_fwd(a, p->io_dtype, pl.items, pl.glds, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(SIGMA_ERR_LAUNCH, "scan_fwd launch failed: %s", hipGetErrorString(e));
     return SIGMA_OK;
 }
+
+namespace {
+bool vec_ok_bwd(const sigma_scan_bwd_params* q) {
+    const sigma_scan_fwd_params* p = &q->fwd;
+    const size_t al = 4 * (size_t)elem_size(p->io_dtype);
+    return vec_ok_fwd(p, false) && aligned_to(q->dout, al) && aligned_to(q->du, al) && aligned_to(q->ddelta, al) &&
+           q->dout_batch_stride % 4 == 0 && q->dout_d_stride % 4 == 0 && q->du_batch_stride % 4 == 0 &&
+           q->du_d_stride % 4 == 0 && q->ddelta_batch_stride % 4 == 0 && q->ddelta_d_stride % 4 == 0 &&
+           (p->n_rev_groups == 0 || p->seqlen % 4 == 0);
+}
+}  // namespace
 
 int64_t sigma_scan_bwd_workspace_bytes(const sigma_scan_bwd_params* q) {
     if (!q) { fail(SIGMA_ERR_NULL_ARG, "params is NULL"); return -1; }
     const sigma_scan_fwd_params* p = &q->fwd;
     if (check_fwd(p, false, false)) return -1;
     if (p->batch == 0 || p->seqlen == 0) return 0;
-    const Plan pl = plan_bwd(p);
-    const int P = (p->dim / p->n_groups) / pl.waves;
+    const Plan pl = plan_bwd(p, true);       // rows per workgroup do not depend on alignment
+    const int P = (p->dim / p->n_groups) / pl.rows;
     if (P <= 1) return 0;
     return (int64_t)2 * P * p->batch * p->n_groups * (int64_t)p->dstate * p->seqlen * (int64_t)sizeof(float);
 }
@@ -224,13 +309,14 @@ int sigma_selective_scan_bwd(const sigma_scan_bwd_params* q, void* stream) {
     if (p->batch == 0 || p->seqlen == 0) return SIGMA_OK;
     if (!q->dout || !q->du || !q->ddelta || !q->dA || !q->dB || !q->dC)
         return fail(SIGMA_ERR_NULL_ARG, "dout/du/ddelta/dA/dB/dC must be non-NULL device pointers");
-    if (p->n_chunks > 1 && !p->x)
-        return fail(SIGMA_ERR_NULL_ARG, "x (forward checkpoints) is required when n_chunks > 1");
+    if (p->seqlen > SIGMA_SCAN_CKPT_PITCH && !p->x)
+        return fail(SIGMA_ERR_NULL_ARG, "x (forward checkpoints) is required when seqlen > %d", SIGMA_SCAN_CKPT_PITCH);
     if ((p->D == nullptr) != (q->dD == nullptr) || (p->delta_bias == nullptr) != (q->ddelta_bias == nullptr))
         return fail(SIGMA_ERR_NULL_ARG, "dD / ddelta_bias must be given exactly when D / delta_bias are");
-    const Plan pl = plan_bwd(p);
-    if (pl.lds > 160 * 1024) return fail(SIGMA_ERR_BAD_SHAPE, "LDS budget exceeded (%zu B)", pl.lds);
-    const int P = (p->dim / p->n_groups) / pl.waves;
+    const bool vec = vec_ok_bwd(q);
+    const Plan pl = plan_bwd(p, vec);
+    if (pl.lds > kLdsLimit) return fail(SIGMA_ERR_BAD_SHAPE, "LDS budget exceeded (%zu B)", pl.lds);
+    const int P = (p->dim / p->n_groups) / pl.rows;
     const int64_t slab = (int64_t)P * p->batch * p->n_groups * (int64_t)p->dstate * p->seqlen;
     if (P > 1) {
         if (!q->workspace || q->workspace_bytes < 2 * slab * (int64_t)sizeof(float))
@@ -238,13 +324,9 @@ int sigma_selective_scan_bwd(const sigma_scan_bwd_params* q, void* stream) {
                         (long long)(2 * slab * (int64_t)sizeof(float)), (long long)q->workspace_bytes);
         if (!aligned_to(q->workspace, 16)) return fail(SIGMA_ERR_BAD_STRIDE, "workspace must be 16-byte aligned");
     }
-    const size_t al = 4 * (size_t)elem_size(p->io_dtype);
-    bool vec = vec_ok_fwd(p, false) && aligned_to(q->dout, al) && aligned_to(q->du, al) && aligned_to(q->ddelta, al) &&
-               q->dout_batch_stride % 4 == 0 && q->dout_d_stride % 4 == 0 && q->du_batch_stride % 4 == 0 &&
-               q->du_d_stride % 4 == 0 && q->ddelta_batch_stride % 4 == 0 && q->ddelta_d_stride % 4 == 0;
     sigma::BwdArgs a;
     std::memset(&a, 0, sizeof(a));
-    a.f = make_fwd_args(p, pl.waves, vec);
+    a.f = make_fwd_args(p, pl.rows, 1, pl.nb, vec);
     a.dout = q->dout; a.du = q->du; a.ddelta = q->ddelta;
     a.dA = q->dA; a.dB = q->dB; a.dC = q->dC; a.dD = q->dD; a.dbias = q->ddelta_bias;
     a.g_bs = q->dout_batch_stride; a.g_ds = q->dout_d_stride;
@@ -259,7 +341,7 @@ int sigma_selective_scan_bwd(const sigma_scan_bwd_params* q, void* stream) {
                     q->dC_group_stride % 4 == 0 && q->dC_dstate_stride % 4 == 0) ? 1 : 0;
     a.ws_dB = P > 1 ? static_cast<float*>(q->workspace) : nullptr;
     a.ws_dC = P > 1 ? static_cast<float*>(q->workspace) + slab : nullptr;
-    hipError_t e = sigma::launch_scan_bwd(a, p->io_dtype, pl.items, pl.waves, static_cast<hipStream_t>(stream));
+    hipError_t e = sigma::launch_scan_bwd(a, p->io_dtype, pl.items, pl.glds, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(SIGMA_ERR_LAUNCH, "scan_bwd launch failed: %s", hipGetErrorString(e));
     return SIGMA_OK;
 }

@@ -5,56 +5,98 @@
 // reverse_scan.cuh:18-401).  Mathematics: SURVEY.md App. E.2.
 //
 // Machine mapping (differs from the reference on purpose):
-//   * one wave per channel row, `nwaves` rows of one (batch, group) per workgroup;
-//   * the sequence is walked chunk by chunk (2048 = the checkpoint pitch of x) from the
-//     end; inside a chunk a cheap forward sweep (fold + wave scan only) rebuilds the state
-//     at every tile start from the chunk checkpoint, then the tiles are processed last to
-//     first: forward replay (x kept in registers) + reverse affine scan of
-//     e = a * dx ("what flows to the element on the left");
+//   * one wave per channel row, R rows of one (batch, group) per workgroup; lane i owns T
+//     consecutive elements of the current tile (T = 10 / 5 / 4: tiles of 640 / 320 / 256);
+//   * the sequence is walked from the end in spans of 1280 elements (the pitch of the state
+//     checkpoints the forward kernel leaves in x).  Inside a span a cheap forward sweep (fold +
+//     wave scan only) rebuilds the state at every tile start, then the tiles are processed last
+//     to first: forward replay (x kept in registers) + reverse affine scan of e = a * dx
+//     ("what flows to the element on the left");
 //   * the reverse scan across lanes is a DPP row_shl scan + uniform row-head fix-up;
-//   * dB / dC are reduced over the workgroup's rows in LDS (ds_add_f32 into a swizzled
-//     [state][k][lane] tile); each workgroup then writes ONE plain coalesced partial per
-//     (n, l) into its slab of a caller-provided workspace and reduce_partials_kernel sums the
-//     P = rows_per_group / rows_per_workgroup slabs in a fixed order -- deterministic, and no
-//     device-scope float atomics (the reference issues one global atomicAdd per row: 192
-//     per element at stage 0).  dA / dD / ddelta_bias are wave-reduced with DPP and hit
-//     memory once per row.
+//   * B/C tiles are streamed into LDS with global_load_lds, double buffered over blocks of NB
+//     states (the next block lands while the current one is computed);
+//   * dB / dC are reduced over the workgroup's rows through per-wave LDS slabs: every thread then
+//     sums one 16-byte column of the R slabs in a fixed order and writes ONE coalesced partial
+//     per (n, l) -- straight into dB/dC when the workgroup owns the whole group, else into its
+//     slab of a caller-provided workspace that reduce_partials_kernel sums in a fixed order.
+//     Deterministic, and no device-scope float atomics (the reference issues one global
+//     atomicAdd per row: 192 per element at stage 0).  The two barriers per state only order
+//     LDS traffic (s_waitcnt lgkmcnt + s_barrier), so they do not drain the B/C stream;
+//   * reversed groups read/write every sequence operand at L-1-l (see scan_fwd.hip).
 #include "scan_device.h"
 #include "scan_launch.h"
 
 namespace sigma {
 
-template <typename io_t, int T>
-__global__ void __launch_bounds__(1024)
-scan_bwd_kernel(const BwdArgs q) {
-    using G = TileGeom<T>;
-    constexpr int NB = kStateBlock;
-    constexpr int TPC = 2048 / G::TILE;               // tiles per checkpoint chunk
+namespace {
+
+// Stage B (and C) rows of states [n0, n0+nbn) of ONE tile into dst laid out [arr][NB][TILE].
+template <typename io_t, int T, bool GLDS>
+__device__ __forceinline__ void stage_tile(float* __restrict__ dst, const io_t* __restrict__ Bg,
+                                           const io_t* __restrict__ Cg, long B_ns, long C_ns, int n0, int nbn, int NB,
+                                           int tile, int L, bool rev, bool vec, bool with_c) {
+    constexpr int TILE = 64 * T;
+    constexpr int CPR = TILE / 4;
+    const int total = (with_c ? 2 : 1) * NB * CPR;
+    const int l0 = tile * TILE;
+    if constexpr (GLDS) {
+        const int lane = threadIdx.x & 63;
+        const int wave = threadIdx.x >> 6;
+        const int nwaves = blockDim.x >> 6;
+        for (int unit = wave; unit * 64 < total; unit += nwaves) {
+            const int ci = unit * 64 + lane;
+            const int row = ci / CPR;                  // arr * NB + nn
+            const int c4 = (ci - row * CPR) * 4;
+            const int arr = row / NB;
+            const int nn = row - arr * NB;
+            const int m = rev ? (L - l0 - TILE + c4) : (l0 + c4);
+            const bool ok = ci < total && nn < nbn && m >= 0 && m < L;
+            const io_t* __restrict__ src = (arr == 0 ? Bg + (long)(n0 + nn) * B_ns : Cg + (long)(n0 + nn) * C_ns) + m;
+            if (ok) __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + unit * 256), 16, 0, 0);
+        }
+    } else {
+        for (int ci = threadIdx.x; ci < total; ci += blockDim.x) {
+            const int row = ci / CPR;
+            const int c4 = (ci - row * CPR) * 4;
+            const int arr = row / NB;
+            const int nn = row - arr * NB;
+            const int m = rev ? (L - l0 - TILE + c4) : (l0 + c4);
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (nn < nbn && m < L && m + 4 > 0) {
+                const io_t* __restrict__ srow = arr == 0 ? Bg + (long)(n0 + nn) * B_ns : Cg + (long)(n0 + nn) * C_ns;
+                load4_guard<io_t>(srow, m, L, vec, v);
+            }
+            *reinterpret_cast<float4*>(dst + (long)ci * 4) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
+}  // namespace
+
+template <typename io_t, int T, bool GLDS, bool REV>
+__device__ __forceinline__ void scan_bwd_body(const BwdArgs& q, float* smem, int b, int row0, int g) {
+    constexpr int TILE = 64 * T;
+    constexpr int TPS = kCkptPitch / TILE;            // tiles per checkpoint span
+    constexpr int VW = vec_width<T>::value;
     const FwdArgs& p = q.f;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int nwaves = blockDim.x >> 6;
-    const int N = p.N, L = p.L;
-    float* sB = smem;
-    float* sC = sB + NB * G::ROW;
-    float* sRed = sC + NB * G::ROW;                   // [nwaves][2][TILE] per-row dB/dC terms of one state
-    float* sX0 = sRed + nwaves * 2 * G::TILE;         // [nwaves][TPC][N] state at tile start
-    float* sR = sX0 + nwaves * TPC * N;               // [nwaves][N] reverse carry a*dx of the tile to the right
-    float* sdA = sR + nwaves * N;                     // [nwaves][N]
-    float* sA = sdA + nwaves * N;                     // [nwaves][N] A[r, n]
+    const int R = blockDim.x >> 6;
+    const int N = p.N, L = p.L, NB = p.NB;
+    const int bufsz = 2 * NB * TILE;
+    float* sBC = smem;                                // [2][2][NB][TILE]
+    float* sRed = sBC + 2 * bufsz;                    // [R][2][TILE] per-row dB/dC terms of one state
+    float* sX0 = sRed + R * 2 * TILE;                 // [R][TPS][N] state at tile start
+    float* sRv = sX0 + R * TPS * N;                   // [R][N] reverse carry a*dx of the tile to the right
+    float* sdA = sRv + R * N;                         // [R][N]
+    float* sA = sdA + R * N;                          // [R][N] A[r, n]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-
-    const int lb = xcd_logical_block(blockIdx.x, gridDim.x);
-    const int b = lb / p.rowblocks;
-    const int rb = lb - b * p.rowblocks;
-    const int row0 = rb * nwaves;
     const int r = row0 + wave;
-    const int g = row0 / p.rows_per_group;
     const bool vec = p.vec_ok != 0;
+    const int ur = p.u_row_mod > 0 ? r % p.u_row_mod : r;
 
-    const io_t* __restrict__ u_row = reinterpret_cast<const io_t*>(p.u) + (long)b * p.u_bs + (long)r * p.u_ds;
+    const io_t* __restrict__ u_row = reinterpret_cast<const io_t*>(p.u) + (long)b * p.u_bs + (long)ur * p.u_ds;
     const io_t* __restrict__ d_row = reinterpret_cast<const io_t*>(p.delta) + (long)b * p.dt_bs + (long)r * p.dt_ds;
     const io_t* __restrict__ g_row = reinterpret_cast<const io_t*>(q.dout) + (long)b * q.g_bs + (long)r * q.g_ds;
     io_t* __restrict__ du_row = reinterpret_cast<io_t*>(q.du) + (long)b * q.du_bs + (long)r * q.du_ds;
@@ -69,29 +111,60 @@ scan_bwd_kernel(const BwdArgs q) {
     const float* __restrict__ x_row = p.x ? p.x + ((long)b * p.dim + r) * (long)p.n_chunks * 2 * N : nullptr;
 
     const long ws_slab = (q.P > 1)
-        ? ((((long)((row0 - g * p.rows_per_group) / nwaves) * p.batch + b) * p.G + g) * (long)N * L) : 0;
+        ? ((((long)((row0 - g * p.rows_per_group) / R) * p.batch + b) * p.G + g) * (long)N * L) : 0;
     for (int n = lane; n < N; n += 64) {
-        sR[wave * N + n] = 0.0f; sdA[wave * N + n] = 0.0f; sA[wave * N + n] = A_row[(long)n * p.A_ns];
+        sRv[wave * N + n] = 0.0f; sdA[wave * N + n] = 0.0f; sA[wave * N + n] = A_row[(long)n * p.A_ns];
     }
+    // never multiply uninitialised LDS bits (stale/NaN) into the padding of the last tile
+    for (int i = tid; i < 2 * bufsz / 4; i += blockDim.x) reinterpret_cast<float4*>(sBC)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
     float dD_acc = 0.0f, dbias_acc = 0.0f;
 
-    const int n_chunks = (L + 2047) >> 11;
-    for (int c = n_chunks - 1; c >= 0; --c) {
-        const int cl0 = c << 11;
-        const int rem = L - cl0;
-        const int ntc = (rem >= 2048) ? TPC : (rem + G::TILE - 1) / G::TILE;
+    const int nsb = (N + NB - 1) / NB;
+    const int nspans = (L + kCkptPitch - 1) / kCkptPitch;
+    auto tiles_in_span = [&](int s) {
+        const int rem = L - s * kCkptPitch;
+        return rem >= kCkptPitch ? TPS : (rem + TILE - 1) / TILE;
+    };
+    StagePlan<T, REV> plan;
+    if constexpr (GLDS) plan.init(NB, 1, L);
+    auto stage = [&](int step, int tile, int sb, bool with_c) {
+        const int n0 = sb * NB;
+        const int nbn = (N - n0 < NB) ? (N - n0) : NB;
+        float* dst = sBC + (step & 1) * bufsz;
+        if constexpr (GLDS) {
+            plan.issue(dst, reinterpret_cast<const float*>(Bg), reinterpret_cast<const float*>(Cg), (int)p.B_ns, (int)p.C_ns,
+                       n0, nbn, tile, L, NB * TILE, with_c);
+        } else {
+            stage_tile<io_t, T, false>(dst, Bg, Cg, p.B_ns, p.C_ns, n0, nbn, NB, tile, L, REV, vec, with_c);
+        }
+    };
 
-        // ================= phase F: state at the start of every tile of this chunk
-        for (int n = lane; n < N; n += 64)
-            sX0[(wave * TPC + 0) * N + n] = (c > 0 && x_row) ? x_row[((long)(c - 1) * N + n) * 2 + 1] : 0.0f;
+    int step = 0;                                      // staging buffer parity
+    {
+        const int nt = tiles_in_span(nspans - 1);      // first step of the whole walk
+        stage(0, (nspans - 1) * TPS + (nt > 1 ? 0 : nt - 1), 0, nt <= 1);
+        __syncthreads();
+    }
+
+    for (int s = nspans - 1; s >= 0; --s) {
+        const int ntc = tiles_in_span(s);
+        const int tile_base = s * TPS;
+
+        // ================= phase F: state at the start of every tile of this span
+        for (int n = lane; n < N; n += 64) {
+            float x0 = 0.0f;
+            if (s > 0 && x_row) { const int ci = s - 1; x0 = x_row[((long)(ci >> 1) * N + n) * 2 + (ci & 1)]; }
+            sX0[(wave * TPS + 0) * N + n] = x0;
+        }
         for (int j = 0; j + 1 < ntc; ++j) {
-            const int l0 = cl0 + j * G::TILE;
+            const int l0 = (tile_base + j) * TILE;
             const int lbase = l0 + lane * T;
             float dl[T], dlu[T];
             {
                 float uv[T], dv[T];
-                load_items<io_t, T>(u_row, lbase, L, vec, uv);
-                load_items<io_t, T>(d_row, lbase, L, vec, dv);
+                load_items<io_t, T, REV>(u_row, lbase, L, vec, uv);
+                load_items<io_t, T, REV>(d_row, lbase, L, vec, dv);
 #pragma unroll
                 for (int k = 0; k < T; ++k) {
                     float d = dv[k] + bias;
@@ -104,56 +177,50 @@ scan_bwd_kernel(const BwdArgs q) {
             float dsum = 0.0f;
 #pragma unroll
             for (int k = 0; k < T; ++k) dsum += dl[k];
-            for (int nb0 = 0; nb0 < N; nb0 += NB) {
-                __syncthreads();
-                for (int idx = tid; idx < NB * (G::TILE / 4); idx += blockDim.x) {
-                    const int nn = idx / (G::TILE / 4);
-                    const int l4 = (idx - nn * (G::TILE / 4)) * 4;
-                    const int n = nb0 + nn;
-                    const int l = l0 + l4;
-                    float bv[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (n < N && l < L) load4<io_t>(Bg + (long)n * p.B_ns + l, vec, L - l, bv);
-                    *reinterpret_cast<float4*>(sB + nn * G::ROW + (l4 / T) * G::LSTR + (l4 % T)) =
-                        make_float4(bv[0], bv[1], bv[2], bv[3]);
-                }
-                __syncthreads();
-                const int nend = (N - nb0 < NB) ? (N - nb0) : NB;
+            for (int sb = 0; sb < nsb; ++sb) {
+                const float* cur = sBC + (step & 1) * bufsz;
+                if (sb + 1 < nsb) stage(step + 1, tile_base + j, sb + 1, false);
+                else if (j + 2 < ntc) stage(step + 1, tile_base + j + 1, 0, false);
+                else stage(step + 1, tile_base + ntc - 1, 0, true);          // first R step
+                const int n0 = sb * NB;
+                const int nend = (N - n0 < NB) ? (N - n0) : NB;
 #pragma unroll 1
                 for (int nn = 0; nn < nend; ++nn) {
-                    const int n = nb0 + nn;
+                    const int n = n0 + nn;
                     const float A2 = sA[wave * N + n] * kLog2e;
-                    const float4* __restrict__ pB = reinterpret_cast<const float4*>(sB + nn * G::ROW + lane * G::LSTR);
                     float xa = 0.0f;
 #pragma unroll
-                    for (int qq = 0; qq < T / 4; ++qq) {
-                        const float4 bv = pB[qq];
-                        const float bq[4] = {bv.x, bv.y, bv.z, bv.w};
+                    for (int qq = 0; qq < T / VW; ++qq) {
+                        float bq[VW];
+                        lds_read_chunk<T, REV>(cur + nn * TILE, lane, qq, bq);
 #pragma unroll
-                        for (int jj = 0; jj < 4; ++jj) {
-                            const int k = 4 * qq + jj;
+                        for (int jj = 0; jj < VW; ++jj) {
+                            const int k = VW * qq + jj;
                             xa = fmaf(fast_exp2(dl[k] * A2), xa, dlu[k] * bq[jj]);
                         }
                     }
-                    float pa = fast_exp2(A2 * dsum);
-                    wave_scan_inclusive(pa, xa);
+                    float sa = A2 * dsum;
+                    wave_scan_inclusive(sa, xa);
                     if (lane == 63) {
-                        const float x0 = sX0[(wave * TPC + j) * N + n];
-                        sX0[(wave * TPC + j + 1) * N + n] = fmaf(pa, x0, xa);
+                        const float x0 = sX0[(wave * TPS + j) * N + n];
+                        sX0[(wave * TPS + j + 1) * N + n] = fmaf(fast_exp2(sa), x0, xa);
                     }
                 }
+                __syncthreads();
+                ++step;
             }
         }
 
-        // ================= phase R: tiles of this chunk, last to first
+        // ================= phase R: tiles of this span, last to first
         for (int j = ntc - 1; j >= 0; --j) {
-            const int l0 = cl0 + j * G::TILE;
+            const int l0 = (tile_base + j) * TILE;
             const int lbase = l0 + lane * T;
             float dl[T], dlu[T], gg[T], sdxB[T], sAx[T];
             {
                 float dv[T], uu[T];
-                load_items<io_t, T>(u_row, lbase, L, vec, uu);
-                load_items<io_t, T>(d_row, lbase, L, vec, dv);
-                load_items<io_t, T>(g_row, lbase, L, vec, gg);
+                load_items<io_t, T, REV>(u_row, lbase, L, vec, uu);
+                load_items<io_t, T, REV>(d_row, lbase, L, vec, dv);
+                load_items<io_t, T, REV>(g_row, lbase, L, vec, gg);
 #pragma unroll
                 for (int k = 0; k < T; ++k) {
                     float d = dv[k] + bias;
@@ -169,150 +236,159 @@ scan_bwd_kernel(const BwdArgs q) {
 #pragma unroll
             for (int k = 0; k < T; ++k) dsum += dl[k];
 
-            for (int nb0 = 0; nb0 < N; nb0 += NB) {
-                __syncthreads();
-                for (int idx = tid; idx < NB * (G::TILE / 4); idx += blockDim.x) {
-                    const int nn = idx / (G::TILE / 4);
-                    const int l4 = (idx - nn * (G::TILE / 4)) * 4;
-                    const int n = nb0 + nn;
-                    const int l = l0 + l4;
-                    float bv[4] = {0.f, 0.f, 0.f, 0.f}, cv[4] = {0.f, 0.f, 0.f, 0.f};
-                    if (n < N && l < L) {
-                        load4<io_t>(Bg + (long)n * p.B_ns + l, vec, L - l, bv);
-                        load4<io_t>(Cg + (long)n * p.C_ns + l, vec, L - l, cv);
-                    }
-                    const int off = nn * G::ROW + (l4 / T) * G::LSTR + (l4 % T);
-                    *reinterpret_cast<float4*>(sB + off) = make_float4(bv[0], bv[1], bv[2], bv[3]);
-                    *reinterpret_cast<float4*>(sC + off) = make_float4(cv[0], cv[1], cv[2], cv[3]);
-                }
-                __syncthreads();
+            // image (memory-order) window of this tile for the dB/dC outputs
+            const int img0 = REV ? (L - l0 - TILE) : l0;
 
-                const int nend = (N - nb0 < NB) ? (N - nb0) : NB;
+            for (int sb = 0; sb < nsb; ++sb) {
+                const float* cur = sBC + (step & 1) * bufsz;
+                if (sb + 1 < nsb) {
+                    stage(step + 1, tile_base + j, sb + 1, true);
+                } else if (j > 0) {
+                    stage(step + 1, tile_base + j - 1, 0, true);
+                } else if (s > 0) {                                          // next span: TPS tiles, F first
+                    stage(step + 1, (s - 1) * TPS, 0, TPS <= 1);
+                }
+                const int n0 = sb * NB;
+                const int nend = (N - n0 < NB) ? (N - n0) : NB;
 #pragma unroll 1
                 for (int nn = 0; nn < nend; ++nn) {
-                    const int n = nb0 + nn;
+                    const int n = n0 + nn;
                     const float An = sA[wave * N + n];
                     const float A2 = An * kLog2e;
-                    const float4* __restrict__ pB = reinterpret_cast<const float4*>(sB + nn * G::ROW + lane * G::LSTR);
-                    const float4* __restrict__ pC = reinterpret_cast<const float4*>(sC + nn * G::ROW + lane * G::LSTR);
-                    float a[T], bb[T], xs[T], gc[T];
-                    // ---- forward replay: x at every element
+                    const float* tB = cur + nn * TILE;
+                    const float* tC = tB + NB * TILE;
+                    float a[T], xs[T], gc[T];
+                    // ---- forward replay: x at every element (xs first holds b, then x)
                     float xa = 0.0f;
 #pragma unroll
-                    for (int qq = 0; qq < T / 4; ++qq) {
-                        const float4 bv = pB[qq];
-                        const float4 cv = pC[qq];
-                        const float bq[4] = {bv.x, bv.y, bv.z, bv.w};
-                        const float cq[4] = {cv.x, cv.y, cv.z, cv.w};
+                    for (int qq = 0; qq < T / VW; ++qq) {
+                        float bq[VW], cq[VW];
+                        lds_read_chunk<T, REV>(tB, lane, qq, bq);
+                        lds_read_chunk<T, REV>(tC, lane, qq, cq);
 #pragma unroll
-                        for (int jj = 0; jj < 4; ++jj) {
-                            const int k = 4 * qq + jj;
+                        for (int jj = 0; jj < VW; ++jj) {
+                            const int k = VW * qq + jj;
                             a[k] = fast_exp2(dl[k] * A2);
-                            bb[k] = dlu[k] * bq[jj];
+                            xs[k] = dlu[k] * bq[jj];
                             gc[k] = gg[k] * cq[jj];
-                            xa = fmaf(a[k], xa, bb[k]);
+                            xa = fmaf(a[k], xa, xs[k]);
                         }
                     }
-                    const float plane = fast_exp2(A2 * dsum);   // this lane's decay product
-                    float pa = plane;
-                    wave_scan_inclusive(pa, xa);
-                    const float pe = wave_prev_lane(pa, 1.0f);
+                    const float slane = A2 * dsum;              // log2 of this lane's decay product
+                    float sa = slane;
+                    wave_scan_inclusive(sa, xa);
+                    const float pe = fast_exp2(wave_prev_lane(sa, 0.0f));
                     const float xe = wave_prev_lane(xa, 0.0f);
-                    float x = fmaf(pe, sX0[(wave * TPC + j) * N + n], xe);
+                    const float xstart = fmaf(pe, sX0[(wave * TPS + j) * N + n], xe);   // state entering the lane
+                    {
+                        float x = xstart;
 #pragma unroll
-                    for (int k = 0; k < T; ++k) { x = fmaf(a[k], x, bb[k]); xs[k] = x; }
+                        for (int k = 0; k < T; ++k) { x = fmaf(a[k], x, xs[k]); xs[k] = x; }
+                    }
 
                     // ---- reverse: e_k = a_k * dx_k,  dx_k = g_k C_k + e_{k+1}
                     float e = 0.0f;
 #pragma unroll
                     for (int k = T - 1; k >= 0; --k) e = a[k] * (gc[k] + e);
-                    float pr = plane;
-                    wave_scan_inclusive_rev(pr, e);              // suffix over lanes >= this one
-                    const float pn = wave_next_lane(pr, 1.0f);
+                    float sr = slane;
+                    wave_scan_inclusive_rev(sr, e);              // suffix over lanes >= this one
+                    const float pn = fast_exp2(wave_next_lane(sr, 0.0f));
                     const float en = wave_next_lane(e, 0.0f);
-                    e = fmaf(pn, sR[wave * N + n], en);          // e entering from the right
+                    e = fmaf(pn, sRv[wave * N + n], en);         // e entering from the right
                     float dAp = 0.0f;
-                    // Reverse replay.  Each lane's per-row terms of dB[n, l] / dC[n, l] go straight to
-                    // this wave's LDS slab (natural l order), four at a time, to keep registers free.
-                    // Then the workgroup's rows are reduced: the first 2*TILE/4 threads add the slabs
-                    // in a fixed order and write ONE coalesced float4 per 4 elements -- straight into
-                    // dB/dC when this workgroup owns the whole group, else into its slab of the
-                    // partial workspace (summed by reduce_partials_kernel).  ds_add_f32 was measured
-                    // at ~1000 cycles per wave instruction on gfx950 and global float atomics at
-                    // ~0.16 TB/s; plain LDS traffic + two barriers per state is far cheaper.
-                    float* __restrict__ slab = sRed + wave * 2 * G::TILE + lane * T;
+                    // Reverse replay.  The per-row terms of dB[n, l] / dC[n, l] go straight to this
+                    // wave's LDS slab (position order), VW at a time, to keep registers free; then
+                    // all threads add the R slabs column-wise.
+                    lds_barrier();                               // slab free (previous state reduced)
+                    {
+                        float* __restrict__ slab = sRed + wave * 2 * TILE + lane * T;
 #pragma unroll
-                    for (int qq = T / 4 - 1; qq >= 0; --qq) {
-                        const float4 bv = pB[qq];                // B again: cheaper than T live registers
-                        const float bq[4] = {bv.x, bv.y, bv.z, bv.w};
-                        float vb[4], vc[4];
+                        for (int qq = T / VW - 1; qq >= 0; --qq) {
+                            float bq[VW], vb[VW], vc[VW];
+                            lds_read_chunk<T, REV>(tB, lane, qq, bq);    // B again: cheaper than T live registers
 #pragma unroll
-                        for (int jj = 3; jj >= 0; --jj) {
-                            const int k = 4 * qq + jj;
-                            const float dx = gc[k] + e;
-                            sdxB[k] = fmaf(dx, bq[jj], sdxB[k]);
-                            const float t = dx * (xs[k] - bb[k]);    // dx * a_k * x_{k-1}
-                            sAx[k] = fmaf(An, t, sAx[k]);
-                            dAp = fmaf(dl[k], t, dAp);
-                            vb[jj] = dx * dlu[k];                    // this row's term of dB[n, l]
-                            vc[jj] = gg[k] * xs[k];                  // this row's term of dC[n, l]
-                            e = a[k] * dx;
+                            for (int jj = VW - 1; jj >= 0; --jj) {
+                                const int k = VW * qq + jj;
+                                const float dx = gc[k] + e;
+                                sdxB[k] = fmaf(dx, bq[jj], sdxB[k]);
+                                const float ax = a[k] * (k > 0 ? xs[k > 0 ? k - 1 : 0] : xstart);   // a_k * x_{k-1}
+                                const float t = dx * ax;
+                                sAx[k] = fmaf(An, t, sAx[k]);
+                                dAp = fmaf(dl[k], t, dAp);
+                                vb[jj] = dx * dlu[k];                    // this row's term of dB[n, l]
+                                vc[jj] = gg[k] * xs[k];                  // this row's term of dC[n, l]
+                                e = a[k] * dx;
+                            }
+                            if constexpr (VW == 4) {
+                                *reinterpret_cast<float4*>(slab + 4 * qq) = make_float4(vb[0], vb[1], vb[2], vb[3]);
+                                *reinterpret_cast<float4*>(slab + TILE + 4 * qq) = make_float4(vc[0], vc[1], vc[2], vc[3]);
+                            } else if constexpr (VW == 2) {
+                                *reinterpret_cast<float2*>(slab + 2 * qq) = make_float2(vb[0], vb[1]);
+                                *reinterpret_cast<float2*>(slab + TILE + 2 * qq) = make_float2(vc[0], vc[1]);
+                            } else {
+                                slab[qq] = vb[0];
+                                slab[TILE + qq] = vc[0];
+                            }
                         }
-                        *reinterpret_cast<float4*>(slab + 4 * qq) = make_float4(vb[0], vb[1], vb[2], vb[3]);
-                        *reinterpret_cast<float4*>(slab + G::TILE + 4 * qq) = make_float4(vc[0], vc[1], vc[2], vc[3]);
                     }
                     dAp = wave_sum(dAp);
                     if (lane == 0) {
-                        sR[wave * N + n] = e;                    // a*dx of the tile's first element
+                        sRv[wave * N + n] = e;                   // a*dx of the tile's first element
                         sdA[wave * N + n] += dAp;
                     }
-                    __syncthreads();
-                    for (int t4 = tid; t4 < 2 * G::TILE / 4; t4 += blockDim.x) {
-                        const int c = t4 / (G::TILE / 4);           // 0: dB, 1: dC
-                        const int l4 = (t4 - c * (G::TILE / 4)) * 4;
+                    lds_barrier();                               // slabs complete
+                    for (int t4 = tid; t4 < 2 * TILE / 4; t4 += blockDim.x) {
+                        const int c = t4 / (TILE / 4);           // 0: dB, 1: dC
+                        const int q4 = (t4 - c * (TILE / 4)) * 4;   // image offset (memory order)
+                        const int p4 = REV ? (TILE - 4 - q4) : q4;  // lowest slab position of the 4
                         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-                        for (int w = 0; w < nwaves; ++w) {
-                            const float4 v = *reinterpret_cast<const float4*>(sRed + w * 2 * G::TILE + c * G::TILE + l4);
+                        for (int w = 0; w < R; ++w) {
+                            const float4 v = *reinterpret_cast<const float4*>(sRed + w * 2 * TILE + c * TILE + p4);
                             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
                         }
-                        const int l = l0 + l4;
-                        if (l < L) {
+                        if (REV) { const float4 t = acc; acc = make_float4(t.w, t.z, t.y, t.x); }
+                        const int m = img0 + q4;
+                        if (m < L && m + 4 > 0) {
                             float* __restrict__ dst;
                             bool vst;
                             if (q.P == 1) {
-                                dst = (c == 0 ? dBg + (long)n * q.dB_ns : dCg + (long)n * q.dC_ns) + l;
-                                vst = q.out_vec_ok != 0;
+                                dst = (c == 0 ? dBg + (long)n * q.dB_ns : dCg + (long)n * q.dC_ns) + m;
+                                vst = q.out_vec_ok != 0 && (m & 3) == 0;
                             } else {
-                                dst = (c == 0 ? q.ws_dB : q.ws_dC) + ws_slab + (long)n * L + l;
-                                vst = (L & 3) == 0;
+                                dst = (c == 0 ? q.ws_dB : q.ws_dC) + ws_slab + (long)n * L + m;
+                                vst = ((L | m) & 3) == 0;
                             }
-                            if (vst && l + 3 < L) {
+                            if (vst && m >= 0 && m + 4 <= L) {
                                 *reinterpret_cast<float4*>(dst) = acc;
                             } else {
                                 const float av[4] = {acc.x, acc.y, acc.z, acc.w};
-                                for (int i = 0; i < 4; ++i) if (l + i < L) dst[i] = av[i];
+                                for (int i = 0; i < 4; ++i) if (m + i >= 0 && m + i < L) dst[i] = av[i];
                             }
                         }
                     }
-                    __syncthreads();
                 }
+                __syncthreads();                                 // next B/C block landed
+                ++step;
             }
             // ---- per-element results
-            float duv[T], ddv[T], dv2[T], uu[T];
-            // softplus' = sigmoid(raw) and the u factors: re-read delta and u (L2-resident) instead
-            // of holding 2T registers across the whole state loop
-            load_items<io_t, T>(d_row, lbase, L, vec, dv2);
-            load_items<io_t, T>(u_row, lbase, L, vec, uu);
+            float duv[T], ddv[T];
+            {
+                // softplus' = sigmoid(raw) and the u factors: re-read delta and u (L2-resident) instead
+                // of holding 2T registers across the whole state loop
+                float dv2[T], uu[T];
+                load_items<io_t, T, REV>(d_row, lbase, L, vec, dv2);
+                load_items<io_t, T, REV>(u_row, lbase, L, vec, uu);
 #pragma unroll
-            for (int k = 0; k < T; ++k) {
-                duv[k] = fmaf(Dd, gg[k], dl[k] * sdxB[k]);
-                float dd = fmaf(uu[k], sdxB[k], sAx[k]);
-                if (p.softplus) { float sg; (void)softplus_ref(dv2[k] + bias, sg); dd *= sg; }
-                ddv[k] = dd;
-                if (lbase + k < L) { dD_acc = fmaf(gg[k], uu[k], dD_acc); dbias_acc += dd; }
+                for (int k = 0; k < T; ++k) {
+                    duv[k] = fmaf(Dd, gg[k], dl[k] * sdxB[k]);
+                    float dd = fmaf(uu[k], sdxB[k], sAx[k]);
+                    if (p.softplus) { float sg; (void)softplus_ref(dv2[k] + bias, sg); dd *= sg; }
+                    ddv[k] = dd;
+                    if (lbase + k < L) { dD_acc = fmaf(gg[k], uu[k], dD_acc); dbias_acc += dd; }
+                }
             }
-            store_items<io_t, T>(du_row, lbase, L, vec, duv);
-            store_items<io_t, T>(dd_row, lbase, L, vec, ddv);
+            store_items<io_t, T, REV>(du_row, lbase, L, vec, duv);
+            store_items<io_t, T, REV>(dd_row, lbase, L, vec, ddv);
         }
     }
 
@@ -324,6 +400,24 @@ scan_bwd_kernel(const BwdArgs q) {
     }
     for (int n = lane; n < N; n += 64)
         atomicAdd(q.dA + (long)r * q.dA_ds + (long)n * q.dA_ns, sdA[wave * N + n]);
+}
+
+// T = 10 keeps ~90 values per lane live (5 per-element accumulators + a, x, g*C per state): it
+// needs ~150 VGPRs, i.e. 3 waves per SIMD = 12 rows per workgroup; T = 4 / 5 fit 16.
+template <int T> struct bwd_max_waves { static constexpr int value = (T >= 10) ? 12 : 16; };
+
+template <typename io_t, int T, bool GLDS>
+__global__ void __launch_bounds__(64 * bwd_max_waves<T>::value)
+scan_bwd_kernel(const BwdArgs q) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int R = blockDim.x >> 6;
+    const int lb = xcd_logical_block(blockIdx.x, gridDim.x);
+    const int b = lb / q.f.rowblocks;
+    const int rb = lb - b * q.f.rowblocks;
+    const int row0 = rb * R;
+    const int g = row0 / q.f.rows_per_group;
+    if (g >= q.f.rev_from_group) scan_bwd_body<io_t, T, GLDS, true>(q, smem, b, row0, g);
+    else scan_bwd_body<io_t, T, GLDS, false>(q, smem, b, row0, g);
 }
 
 // out[b, g, n, l] = sum_p ws[p][b][g][n][l]   (deterministic order; 4 elements per thread)
@@ -364,17 +458,17 @@ reduce_partials_kernel(const float* __restrict__ wsB, const float* __restrict__ 
     }
 }
 
-template <typename io_t, int T>
-static hipError_t launch_bwd_t(const BwdArgs& a, int nwaves, hipStream_t stream) {
-    const size_t lds = bwd_lds_bytes(T, nwaves, a.f.N);
+template <typename io_t, int T, bool GLDS>
+static hipError_t launch_bwd_t(const BwdArgs& a, hipStream_t stream) {
+    const size_t lds = bwd_lds_bytes(T, a.f.R, a.f.NB, a.f.N);
     const int grid = a.f.rowblocks * a.f.batch;
-    auto kern = scan_bwd_kernel<io_t, T>;
+    auto kern = scan_bwd_kernel<io_t, T, GLDS>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(nwaves * 64), lds, stream, a);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(a.f.R * 64), lds, stream, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || a.P == 1) return e;
     const long per = (long)a.f.batch * a.f.G * a.f.N * a.f.L;
@@ -387,20 +481,21 @@ static hipError_t launch_bwd_t(const BwdArgs& a, int nwaves, hipStream_t stream)
     return hipGetLastError();
 }
 
-template <typename io_t>
-static hipError_t launch_bwd_io(const BwdArgs& a, int T, int nwaves, hipStream_t stream) {
+template <typename io_t, bool GLDS>
+static hipError_t launch_bwd_io(const BwdArgs& a, int T, hipStream_t stream) {
     switch (T) {
-        case 4: return launch_bwd_t<io_t, 4>(a, nwaves, stream);
-        case 8: return launch_bwd_t<io_t, 8>(a, nwaves, stream);
+        case 4: return launch_bwd_t<io_t, 4, GLDS>(a, stream);
+        case 5: return launch_bwd_t<io_t, 5, GLDS>(a, stream);
+        case 10: return launch_bwd_t<io_t, 10, GLDS>(a, stream);
         default: return hipErrorInvalidValue;
     }
 }
 
-hipError_t launch_scan_bwd(const BwdArgs& a, int dtype, int T, int nwaves, hipStream_t stream) {
+hipError_t launch_scan_bwd(const BwdArgs& a, int dtype, int T, bool glds, hipStream_t stream) {
     switch (dtype) {
-        case 0: return launch_bwd_io<float>(a, T, nwaves, stream);
-        case 1: return launch_bwd_io<f16_t>(a, T, nwaves, stream);
-        case 2: return launch_bwd_io<bf16_t>(a, T, nwaves, stream);
+        case 0: return glds ? launch_bwd_io<float, true>(a, T, stream) : launch_bwd_io<float, false>(a, T, stream);
+        case 1: return launch_bwd_io<f16_t, false>(a, T, stream);
+        case 2: return launch_bwd_io<bf16_t, false>(a, T, stream);
         default: return hipErrorInvalidValue;
     }
 }

@@ -12,7 +12,6 @@ namespace sigma {
 constexpr float kLog2e = 1.4426950408889634f;
 constexpr float kLn2 = 0.6931471805599453f;
 constexpr int kWave = 64;
-constexpr int kStateBlock = 4;   // states whose B/C rows are staged in LDS at a time
 
 // ------------------------------------------------------------------ io types
 struct f16_t { uint16_t bits; };
@@ -45,76 +44,129 @@ template <> struct io_traits<bf16_t> {
     }
 };
 
-// 4 consecutive, fully valid, vector-aligned elements (16 B for f32, 8 B for 16-bit types)
-template <typename io_t>
-__device__ __forceinline__ void load4_vec(const io_t* __restrict__ p, float (&v)[4]) {
-    if constexpr (sizeof(io_t) == 4) {
-        const float4 t = *reinterpret_cast<const float4*>(p);
-        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+// ---- lane-blocked row access ------------------------------------------------------------
+// A lane owns T consecutive SCAN POSITIONS starting at lbase.  In a forward group position p
+// is memory index p; in a reversed group (rev) position p is memory index L-1-p, so the lane's
+// T positions are the T consecutive memory elements [L-lbase-T, L-lbase) in reverse order.
+// Fast path (whole segment in range, `vec`): vector loads of VW = 4 / 2 / 1 elements according
+// to the divisibility of T (T = 20, 4 -> 16 B; T = 10 -> 8 B; T = 5 -> 4 B for f32).
+template <int T> struct vec_width { static constexpr int value = (T % 4 == 0) ? 4 : ((T % 2 == 0) ? 2 : 1); };
+
+template <typename io_t, int VW>
+__device__ __forceinline__ void load_vw(const io_t* __restrict__ p, float* v) {
+    if constexpr (VW == 1) {
+        v[0] = io_traits<io_t>::to_float(p[0]);
+    } else if constexpr (sizeof(io_t) == 4) {
+        if constexpr (VW == 4) { const float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+        else { const float2 t = *reinterpret_cast<const float2*>(p); v[0] = t.x; v[1] = t.y; }
     } else {
-        const uint2 t = *reinterpret_cast<const uint2*>(p);
-        io_t e0, e1, e2, e3;
-        e0.bits = static_cast<uint16_t>(t.x & 0xffffu); e1.bits = static_cast<uint16_t>(t.x >> 16);
-        e2.bits = static_cast<uint16_t>(t.y & 0xffffu); e3.bits = static_cast<uint16_t>(t.y >> 16);
-        v[0] = io_traits<io_t>::to_float(e0); v[1] = io_traits<io_t>::to_float(e1);
-        v[2] = io_traits<io_t>::to_float(e2); v[3] = io_traits<io_t>::to_float(e3);
+        io_t e[VW];
+        if constexpr (VW == 4) {
+            const uint2 t = *reinterpret_cast<const uint2*>(p);
+            e[0].bits = static_cast<uint16_t>(t.x & 0xffffu); e[1].bits = static_cast<uint16_t>(t.x >> 16);
+            e[2].bits = static_cast<uint16_t>(t.y & 0xffffu); e[3].bits = static_cast<uint16_t>(t.y >> 16);
+        } else {
+            const uint32_t t = *reinterpret_cast<const uint32_t*>(p);
+            e[0].bits = static_cast<uint16_t>(t & 0xffffu); e[1].bits = static_cast<uint16_t>(t >> 16);
+        }
+#pragma unroll
+        for (int i = 0; i < VW; ++i) v[i] = io_traits<io_t>::to_float(e[i]);
     }
 }
 
-template <typename io_t>
-__device__ __forceinline__ void store4_vec(io_t* __restrict__ p, const float (&v)[4]) {
-    if constexpr (sizeof(io_t) == 4) {
-        *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+template <typename io_t, int VW>
+__device__ __forceinline__ void store_vw(io_t* __restrict__ p, const float* v) {
+    if constexpr (VW == 1) {
+        p[0] = io_traits<io_t>::from_float(v[0]);
+    } else if constexpr (sizeof(io_t) == 4) {
+        if constexpr (VW == 4) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+        else *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1]);
     } else {
         const uint32_t lo = static_cast<uint32_t>(io_traits<io_t>::from_float(v[0]).bits) |
                             (static_cast<uint32_t>(io_traits<io_t>::from_float(v[1]).bits) << 16);
-        const uint32_t hi = static_cast<uint32_t>(io_traits<io_t>::from_float(v[2]).bits) |
-                            (static_cast<uint32_t>(io_traits<io_t>::from_float(v[3]).bits) << 16);
-        *reinterpret_cast<uint2*>(p) = make_uint2(lo, hi);
+        if constexpr (VW == 4) {
+            const uint32_t hi = static_cast<uint32_t>(io_traits<io_t>::from_float(v[2]).bits) |
+                                (static_cast<uint32_t>(io_traits<io_t>::from_float(v[3]).bits) << 16);
+            *reinterpret_cast<uint2*>(p) = make_uint2(lo, hi);
+        } else {
+            *reinterpret_cast<uint32_t*>(p) = lo;
+        }
     }
 }
 
-// 4 consecutive elements of which the first nvalid (may be <= 0 or > 4) exist; rest read as 0
-template <typename io_t>
-__device__ __forceinline__ void load4(const io_t* __restrict__ p, bool vec, int nvalid, float (&v)[4]) {
-    if (vec && nvalid >= 4) {
-        load4_vec<io_t>(p, v);
-    } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = (i < nvalid) ? io_traits<io_t>::to_float(p[i]) : 0.0f;
-    }
-}
-
-// lane-blocked row access: lane owns T consecutive elements starting at lbase.  The fast
-// path (whole segment in range, rows vector-aligned) is branch-free vector traffic; the
-// guarded scalar path only runs in the ragged last tile or for unaligned tensors.
-template <typename io_t, int T>
+template <typename io_t, int T, bool REV>
 __device__ __forceinline__ void load_items(const io_t* __restrict__ row, int lbase, int L, bool vec, float (&v)[T]) {
+    constexpr int VW = vec_width<T>::value;
     if (vec && lbase + T <= L) {
+        const io_t* __restrict__ src = row + (REV ? (L - lbase - T) : lbase);
 #pragma unroll
-        for (int q = 0; q < T / 4; ++q) {
-            float t[4];
-            load4_vec<io_t>(row + lbase + 4 * q, t);
-            v[4 * q + 0] = t[0]; v[4 * q + 1] = t[1]; v[4 * q + 2] = t[2]; v[4 * q + 3] = t[3];
+        for (int q = 0; q < T / VW; ++q) {
+            float t[VW];
+            load_vw<io_t, VW>(src + VW * q, t);
+#pragma unroll
+            for (int j = 0; j < VW; ++j) v[REV ? (T - 1 - (VW * q + j)) : (VW * q + j)] = t[j];
         }
     } else {
 #pragma unroll
-        for (int k = 0; k < T; ++k) v[k] = (lbase + k < L) ? io_traits<io_t>::to_float(row[lbase + k]) : 0.0f;
+        for (int k = 0; k < T; ++k) {
+            const int pos = lbase + k;
+            v[k] = (pos < L) ? io_traits<io_t>::to_float(row[REV ? (L - 1 - pos) : pos]) : 0.0f;
+        }
     }
 }
 
-template <typename io_t, int T>
+template <typename io_t, int T, bool REV>
 __device__ __forceinline__ void store_items(io_t* __restrict__ row, int lbase, int L, bool vec, const float (&v)[T]) {
+    constexpr int VW = vec_width<T>::value;
     if (vec && lbase + T <= L) {
+        io_t* __restrict__ dst = row + (REV ? (L - lbase - T) : lbase);
 #pragma unroll
-        for (int q = 0; q < T / 4; ++q) {
-            const float t[4] = {v[4 * q + 0], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]};
-            store4_vec<io_t>(row + lbase + 4 * q, t);
+        for (int q = 0; q < T / VW; ++q) {
+            float t[VW];
+#pragma unroll
+            for (int j = 0; j < VW; ++j) t[j] = v[REV ? (T - 1 - (VW * q + j)) : (VW * q + j)];
+            store_vw<io_t, VW>(dst + VW * q, t);
         }
     } else {
 #pragma unroll
-        for (int k = 0; k < T; ++k) if (lbase + k < L) row[lbase + k] = io_traits<io_t>::from_float(v[k]);
+        for (int k = 0; k < T; ++k) {
+            const int pos = lbase + k;
+            if (pos < L) row[REV ? (L - 1 - pos) : pos] = io_traits<io_t>::from_float(v[k]);
+        }
     }
+}
+
+// 4 consecutive memory elements starting at index m (may be < 0 or reach >= L); missing ones read 0
+template <typename io_t>
+__device__ __forceinline__ void load4_guard(const io_t* __restrict__ row, int m, int L, bool vec, float (&v)[4]) {
+    if (vec && m >= 0 && m + 4 <= L) {
+        load_vw<io_t, 4>(row + m, v);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = (m + i >= 0 && m + i < L) ? io_traits<io_t>::to_float(row[m + i]) : 0.0f;
+    }
+}
+
+// ---- staged B/C tiles in LDS -------------------------------------------------------------
+// The LDS image of one (state, tile) is TILE = 64*T floats in MEMORY order (for a reversed
+// group: memory [L-l0-TILE, L-l0)), unpadded -- which is what global_load_lds can produce
+// (wave-uniform LDS base + lane*16 B).  A lane reads its T consecutive floats with
+// ds_read_b128 / b64 / b32; for T in {4, 5, 10, 20} the lane stride (T dwords) makes every
+// hardware lane group hit distinct banks, so no padding or swizzle is needed
+// (MI355X_MICROARCH.md LDS table: b128 groups of 16 lanes over 64 banks, stride 20 -> 16
+// distinct multiples of 4; b64 stride 10 -> 32 distinct even banks; b32 stride 5 -> 32 distinct).
+// positions k = VW*q .. VW*q+VW-1 of the lane's segment (VW = vec_width<T>)
+template <int T, bool REV>
+__device__ __forceinline__ void lds_read_chunk(const float* __restrict__ tile, int lane, int q,
+                                               float (&v)[vec_width<T>::value]) {
+    constexpr int VW = vec_width<T>::value;
+    const float* __restrict__ src = REV ? tile + (63 - lane) * T + (T - (q + 1) * VW) : tile + lane * T + q * VW;
+    float t[VW];
+    if constexpr (VW == 4) { const float4 x = *reinterpret_cast<const float4*>(src); t[0] = x.x; t[1] = x.y; t[2] = x.z; t[3] = x.w; }
+    else if constexpr (VW == 2) { const float2 x = *reinterpret_cast<const float2*>(src); t[0] = x.x; t[1] = x.y; }
+    else { t[0] = src[0]; }
+#pragma unroll
+    for (int j = 0; j < VW; ++j) v[j] = t[REV ? (VW - 1 - j) : j];
 }
 
 // ------------------------------------------------------------------ math
@@ -127,13 +179,15 @@ __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcp
 // (selective_scan_bwd_kernel.cuh:234-247).  log1p via Kahan's correction so that
 // tiny deltas (model init: softplus^-1 of 1e-3) keep full relative precision.
 __device__ __forceinline__ float softplus_ref(float raw, float& sig) {
-    if (raw > 20.0f) { sig = 1.0f; return raw; }
+    // branch-free: both arms are cheap and selects keep the unrolled per-element code straight-line
     const float e = fast_exp2(raw * kLog2e);
     const float w = 1.0f + e;
     const float lw = fast_log2(w) * kLn2;
     const float wm1 = w - 1.0f;
-    sig = e * fast_rcp(w);
-    return (wm1 == 0.0f) ? e : lw * (e * fast_rcp(wm1));
+    const float sp = (wm1 == 0.0f) ? e : lw * (e * fast_rcp(wm1));
+    const bool big = raw > 20.0f;
+    sig = big ? 1.0f : e * fast_rcp(w);
+    return big ? raw : sp;
 }
 
 // ------------------------------------------------------------------ DPP plumbing
@@ -150,26 +204,34 @@ constexpr int DPP_ROW_SHL1 = 0x101, DPP_ROW_SHL2 = 0x102, DPP_ROW_SHL4 = 0x104, 
 constexpr int DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143;
 constexpr int DPP_WAVE_SHR1 = 0x138, DPP_WAVE_SHL1 = 0x130;
 
-// The scan element is the affine map  s -> p*s + x  ("decay p, injected state x").
-// compose(earlier, later) = (p_l*p_e, p_l*x_e + x_l)          (selective_scan_common.h:92-96)
-#define SIGMA_SCAN_STEP(CTRL, MASK)                                   \
-    {                                                                 \
-        const float pe_ = dpp_take<CTRL, MASK>(1.0f, p);              \
-        const float xe_ = dpp_take<CTRL, MASK>(0.0f, x);              \
-        x = fmaf(p, xe_, x);                                          \
-        p = p * pe_;                                                  \
-    }
+// The scan element is the affine map  state -> p*state + x  ("decay p, injected state x"),
+// compose(earlier, later) = (p_l*p_e, p_l*x_e + x_l)          (selective_scan_common.h:92-96).
+// The decay is carried as s = log2(p) (a sum of delta*A*log2e terms): composition ADDS s, whose
+// identity 0 is exactly what a DPP read with bound_ctrl returns for a missing source lane, and x's
+// identity is 0 too -- so one scan step is three instructions with the lane shuffle folded into
+// the arithmetic (v_exp_f32, v_add_f32_dpp, v_fmac_f32_dpp) instead of two v_mov_dpp + mul + fma
+// with explicit identities.  Written in asm because hipcc does not fold DPP moves into VOP2 users
+// here; wait states are inside the string (2 between a VALU write and a DPP read of the same
+// VGPR, 1 between v_exp and a use of its result; the instruction order provides them).
+#define SIGMA_SCAN_STEP_ASM(CTRL)                                  \
+    "v_exp_f32 %2, %0\n\t"                                         \
+    "v_add_f32_dpp %0, %0, %0 " CTRL "\n\t"                        \
+    "v_fmac_f32_dpp %1, %1, %2 " CTRL "\n\t"
 
-// inclusive scan over the 64 lanes in lane order (lane 0 earliest)
-__device__ __forceinline__ void wave_scan_inclusive(float& p, float& x) {
-    SIGMA_SCAN_STEP(DPP_ROW_SHR1, 0xF)
-    SIGMA_SCAN_STEP(DPP_ROW_SHR2, 0xF)
-    SIGMA_SCAN_STEP(DPP_ROW_SHR4, 0xF)
-    SIGMA_SCAN_STEP(DPP_ROW_SHR8, 0xF)
-    SIGMA_SCAN_STEP(DPP_ROW_BCAST15, 0xA)
-    SIGMA_SCAN_STEP(DPP_ROW_BCAST31, 0xC)
+// inclusive scan over the 64 lanes in lane order (lane 0 earliest); s = log2 of the decay
+__device__ __forceinline__ void wave_scan_inclusive(float& s, float& x) {
+    float p;
+    asm(
+        "s_nop 1\n\t"
+        SIGMA_SCAN_STEP_ASM("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+        SIGMA_SCAN_STEP_ASM("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+        SIGMA_SCAN_STEP_ASM("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+        SIGMA_SCAN_STEP_ASM("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+        SIGMA_SCAN_STEP_ASM("row_bcast:15 row_mask:0xa bank_mask:0xf")
+        SIGMA_SCAN_STEP_ASM("row_bcast:31 row_mask:0xc bank_mask:0xf")
+        "s_nop 1\n\t"
+        : "+v"(s), "+v"(x), "=&v"(p));
 }
-#undef SIGMA_SCAN_STEP
 
 // value of the previous lane (lane 0 gets `first`)
 __device__ __forceinline__ float wave_prev_lane(float v, float first) {
@@ -186,37 +248,34 @@ __device__ __forceinline__ float lane_bcast(float v, int lane) {
 
 // Suffix ("reverse") inclusive scan: lane 63 is the EARLIEST element of the scan
 // order, lane 0 the last.  Element i composes with everything at higher lanes:
-//   (p_i, x_i) <- x_i + p_i * X_{i+1},  p_i * P_{i+1}
+//   (s_i, x_i) <- (s_i + S_{i+1}, x_i + 2^{s_i} * X_{i+1})
 // Rows are handled with row_shl; the cross-row part uses readlane of the row
 // heads (lanes 16/32/48), all wave-uniform.
-__device__ __forceinline__ void wave_scan_inclusive_rev(float& p, float& x) {
-#define SIGMA_RSTEP(CTRL)                                             \
-    {                                                                 \
-        const float pe_ = dpp_take<CTRL, 0xF>(1.0f, p);               \
-        const float xe_ = dpp_take<CTRL, 0xF>(0.0f, x);               \
-        x = fmaf(p, xe_, x);                                          \
-        p = p * pe_;                                                  \
-    }
-    SIGMA_RSTEP(DPP_ROW_SHL1)
-    SIGMA_RSTEP(DPP_ROW_SHL2)
-    SIGMA_RSTEP(DPP_ROW_SHL4)
-    SIGMA_RSTEP(DPP_ROW_SHL8)
-#undef SIGMA_RSTEP
+__device__ __forceinline__ void wave_scan_inclusive_rev(float& s, float& x) {
+    float p;
+    asm(
+        "s_nop 1\n\t"
+        SIGMA_SCAN_STEP_ASM("row_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+        SIGMA_SCAN_STEP_ASM("row_shl:2 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+        SIGMA_SCAN_STEP_ASM("row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+        SIGMA_SCAN_STEP_ASM("row_shl:8 row_mask:0xf bank_mask:0xf bound_ctrl:0")
+        "s_nop 1\n\t"
+        : "+v"(s), "+v"(x), "=&v"(p));
     // row aggregates sit at the first lane of each row (lanes 0,16,32,48)
     const int lane = threadIdx.x & 63;
-    const float p3 = lane_bcast(p, 48), x3 = lane_bcast(x, 48);
-    const float p2 = lane_bcast(p, 32), x2 = lane_bcast(x, 32);
-    const float p1 = lane_bcast(p, 16), x1 = lane_bcast(x, 16);
+    const float s3 = lane_bcast(s, 48), x3 = lane_bcast(x, 48);
+    const float s2 = lane_bcast(s, 32), x2 = lane_bcast(x, 32);
+    const float s1 = lane_bcast(s, 16), x1 = lane_bcast(x, 16);
     // suffix aggregates of whole rows: S3 = row3, S2 = row2 o S3, S1 = row1 o S2
-    const float sx3 = x3, sp3 = p3;
-    const float sx2 = fmaf(p2, sx3, x2), sp2 = p2 * sp3;
-    const float sx1 = fmaf(p1, sx2, x1), sp1 = p1 * sp2;
+    const float sx2 = fmaf(fast_exp2(s2), x3, x2), ss2 = s2 + s3;
+    const float sx1 = fmaf(fast_exp2(s1), sx2, x1), ss1 = s1 + ss2;
     const int row = lane >> 4;
-    const float tx = row == 0 ? sx1 : (row == 1 ? sx2 : (row == 2 ? sx3 : 0.0f));
-    const float tp = row == 0 ? sp1 : (row == 1 ? sp2 : (row == 2 ? sp3 : 1.0f));
-    x = fmaf(p, tx, x);
-    p = p * tp;
+    const float tx = row == 0 ? sx1 : (row == 1 ? sx2 : (row == 2 ? x3 : 0.0f));
+    const float ts = row == 0 ? ss1 : (row == 1 ? ss2 : (row == 2 ? s3 : 0.0f));
+    x = fmaf(fast_exp2(s), tx, x);
+    s = s + ts;
 }
+#undef SIGMA_SCAN_STEP_ASM
 
 // plain sum over the wave, result in every lane
 __device__ __forceinline__ float wave_sum(float v) {
@@ -241,11 +300,92 @@ __device__ __forceinline__ int xcd_logical_block(int hw, int nblk) {
     return base + slot;
 }
 
+// workgroup barrier that orders LDS traffic only: s_waitcnt lgkmcnt(0) + s_barrier.  Unlike
+// __syncthreads() it does not wait for outstanding global loads / LDS-DMA (vmcnt), so a
+// global_load_lds stream issued earlier keeps flying across it.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// ---- B/C staging with global_load_lds ----------------------------------------------------
+// The LDS image of one staging block is [arr = B, C][rows][TILE] floats (rows = NB states x W
+// tiles), filled in units of 64 chunks of 16 B: wave v issues units v, v + nwaves, ... and lane i
+// of a unit owns chunk ci = unit*64 + i.  Which (array, state, tile, offset) a chunk is does not
+// change from block to block, so the decomposition (integer divisions by run-time values) is
+// done ONCE per kernel into a few registers; issuing a block is then ~10 VALU per 16-byte load.
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+constexpr int kStageMaxIt = 2;     // units of 64 chunks a wave issues per array and block (host-checked)
+
+template <int T, bool REV>
+struct StagePlan {
+    static constexpr int TILE = 64 * T;
+    static constexpr int CPR = TILE / 4;
+    int moff[kStageMaxIt];     // memory index of the chunk for tile 0
+    int nn[kStageMaxIt];       // state index inside the block; 0xffff = unused entry
+    int nit;                   // entries in use (wave-uniform, <= kStageMaxIt: checked on the host)
+
+    __device__ __forceinline__ void init(int NB, int W, int L) {
+        const int lane = threadIdx.x & 63;
+        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const int nwaves = blockDim.x >> 6;
+        const int total = NB * W * CPR;                // chunks of ONE array (B and C share the pattern)
+        const int units = (total + 63) / 64;
+        nit = (units + nwaves - 1) / nwaves;
+#pragma unroll
+        for (int i = 0; i < kStageMaxIt; ++i) {
+            const int ci = (wave + i * nwaves) * 64 + lane;
+            const int row = ci / CPR;                  // nn * W + w
+            const int c4 = (ci - row * CPR) * 4;
+            const int n = row / W;
+            const int w = row - n * W;
+            moff[i] = REV ? (L - w * TILE - TILE + c4) : (w * TILE + c4);
+            nn[i] = (ci < total) ? n : 0xffff;
+        }
+    }
+
+    // states [n0, n0 + nbn) of the W tiles starting at tile0 -> dst ([arr][NB][W][TILE] image);
+    // Bg / Cg are wave-uniform (batch, group) bases, offsets inside one slice fit 31 bits (host-checked)
+    __device__ __forceinline__ void issue(float* dst, const float* Bg, const float* Cg, int B_ns, int C_ns, int n0,
+                                          int nbn, int tile0, int L, int arr_stride, bool with_c) const {
+        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const int nwaves = blockDim.x >> 6;
+        const int t0e = REV ? -(tile0 * TILE) : tile0 * TILE;
+#pragma unroll
+        for (int i = 0; i < kStageMaxIt; ++i) {
+            if (i < nit) {
+                const int m = moff[i] + t0e;
+                const bool ok = nn[i] < nbn && m >= 0 && m < L;           // L % 4 == 0: whole chunk in range
+                float* d = dst + (wave + i * nwaves) * 256;
+                if (ok) {
+                    const unsigned ob = (unsigned)((n0 + nn[i]) * B_ns + m) * 4u;
+                    __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const char*>(Bg) + ob), (lptr_t)d, 16, 0, 0);
+                    if (with_c) {
+                        const unsigned oc = (unsigned)((n0 + nn[i]) * C_ns + m) * 4u;
+                        __builtin_amdgcn_global_load_lds((gptr_t)(reinterpret_cast<const char*>(Cg) + oc),
+                                                         (lptr_t)(d + arr_stride), 16, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+};
+
 // ------------------------------------------------------------------ kernel args
+constexpr int kCkptPitch = 1280;   // elements between state checkpoints in x (see include/sigma_scan.h)
+
 struct FwdArgs {
     const void* u; const void* delta; const float* A; const void* B; const void* C;
     const float* D; const float* bias; void* out; float* x;
     int batch, dim, L, N, G, n_chunks, rows_per_group, softplus, vec_ok, rowblocks;
+    int R;                // rows per workgroup
+    int W;                // consecutive tiles per workgroup ("super-tile"); waves = R * W
+    int NB;               // states staged per step
+    int rev_from_group;   // groups g >= this run over the sequence in reverse memory order (>= G: none)
+    int u_row_mod;        // > 0: u row of channel row r is r % u_row_mod (CrossScan without the 4x copy)
     long u_bs, u_ds, dt_bs, dt_ds, A_ds, A_ns;
     long B_bs, B_gs, B_ns, C_bs, C_gs, C_ns, o_bs, o_ds;
 };
@@ -255,17 +395,10 @@ struct BwdArgs {
     const void* dout; void* du; void* ddelta;
     float* dA; float* dB; float* dC; float* dD; float* dbias;
     float* ws_dB; float* ws_dC;     // [P][batch][G][N][L] per-workgroup partials (P > 1)
-    int P;                          // workgroups per (batch, group) = rows_per_group / nwaves
-    int out_vec_ok;                 // dB/dC rows are 16-byte aligned (float4 stores legal when P == 1)
+    int P;                          // workgroups per (batch, group) = rows_per_group / R
+    int out_vec_ok;                 // dB/dC rows are 16-byte aligned
     long g_bs, g_ds, du_bs, du_ds, dd_bs, dd_ds, dA_ds, dA_ns;
     long dB_bs, dB_gs, dB_ns, dC_bs, dC_gs, dC_ns;
-};
-
-template <int T> struct TileGeom {
-    static constexpr int PAD = (T >= 8) ? 4 : 0;     // keeps ds_read_b128 conflict-free
-    static constexpr int LSTR = T + PAD;             // floats per lane slot
-    static constexpr int ROW = kWave * LSTR;         // floats per staged state row
-    static constexpr int TILE = kWave * T;           // sequence elements per tile
 };
 
 }  // namespace sigma

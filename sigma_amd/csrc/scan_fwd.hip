@@ -4,200 +4,308 @@
 // models/encoders/selective_scan/csrc/selective_scan/selective_scan_fwd_kernel.cuh:62-206).
 // Same mathematics, different machine mapping:
 //
-//   * one WAVE per channel row; a workgroup is `nwaves` rows of the SAME (batch, group),
-//     so the group's B/C tile is fetched from HBM/L2 once per workgroup and shared via LDS
-//     (the reference re-reads B/C from global for every row and every state);
-//   * the sequence is walked in tiles of 64*T elements; lane i owns T consecutive
-//     elements; per state n: serial fold over the lane's T elements (decay a, input b kept
-//     in registers), one DPP wave scan of the 64 lane aggregates, serial replay with the
-//     right incoming state.  The lane decay product is exp2(A * sum(delta)) -- one
-//     transcendental instead of a T-long product;
-//   * B/C are staged kStateBlock states at a time in a padded, lane-blocked LDS layout that
-//     makes the ds_read_b128 of a lane's T consecutive values bank-conflict free;
-//   * running state between tiles lives in LDS (one float per (row, state)), checkpoints
-//     every 2048 elements go to x exactly as the reference lays them out
-//     (selective_scan.cpp:225-228, fwd_kernel.cuh:181-184).
+//   * a workgroup is R channel rows of ONE (batch, group) times W consecutive sequence tiles
+//     (R*W <= 16 waves); wave (wr, wt) owns row wr and tile wt of the current "super-tile" of
+//     W*64*T elements and the workgroup walks the sequence super-tile by super-tile.  Many rows
+//     (training batches): R = 16, W = 1.  Few rows (one image per GPU): W > 1 splits the sequence
+//     inside the workgroup so that 256 CUs still get 15-16 waves each;
+//   * lane i owns T consecutive elements of its tile.  Per state n: serial fold over the lane's
+//     T elements (decay a and input b stay in registers), ONE DPP wave scan of the 64 lane
+//     aggregates, serial replay with the true incoming state.  The lane decay product is
+//     exp2(A * sum(delta)) -- one transcendental instead of a T-long product.  With W > 1 the
+//     tile aggregates of a row meet in LDS (one extra barrier per state) and each wave composes
+//     its predecessors' (decay, state) pairs before the replay;
+//   * T is 20 / 10 / 5 / 4 (tiles of 1280 / 640 / 320 / 256): the model's sequence lengths are
+//     multiples of 300 (15x20 .. 120x160), which power-of-two tiles pad by up to 40 %;
+//   * the group's B/C tile is shared by the R rows through LDS: global_load_lds (async, no VGPR
+//     round trip) into an unpadded memory-order image, double buffered over blocks of NB
+//     states, so the next block streams in while the current one is computed and there is ONE
+//     barrier per block.  u/delta of the next super-tile are prefetched into registers during
+//     the last block of the current one;
+//   * reversed groups (CrossScan directions 2, 3) read every sequence operand at L-1-l and write
+//     out there, so no flipped copies of x / delta / B / C have to exist (vmamba.py:80-121);
+//   * running state between super-tiles lives in LDS; states every 1280 elements go to x
+//     (layout in include/sigma_scan.h) for the backward pass.
 #include "scan_device.h"
 #include "scan_launch.h"
 
 namespace sigma {
 
-template <typename io_t, int T>
-__global__ void __launch_bounds__(1024)
-scan_fwd_kernel(const FwdArgs p) {
-    using G = TileGeom<T>;
-    constexpr int NB = kStateBlock;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* sB = smem;
-    float* sC = smem + NB * G::ROW;
-    float* sCA = smem + 2 * NB * G::ROW;              // [nwaves][N] float2 {A[r,n]*log2(e), running state x[n]}
+namespace {
 
+// Stage B and C rows of states [n0, n0+nbn) for the W tiles starting at tile index tile0 into
+// `dst` laid out [arr = B,C][NB][W][TILE] (floats, memory order).
+template <typename io_t, int T, bool GLDS>
+__device__ __forceinline__ void stage_bc(float* __restrict__ dst, const io_t* __restrict__ Bg,
+                                         const io_t* __restrict__ Cg, long B_ns, long C_ns, int n0, int nbn, int NB,
+                                         int W, int tile0, int L, bool rev, bool vec, bool with_c) {
+    constexpr int TILE = 64 * T;
+    constexpr int CPR = TILE / 4;                      // 16-byte chunks per (state, tile) row
+    const int rows = NB * W;                           // rows per array in the LDS image
+    const int total = (with_c ? 2 : 1) * rows * CPR;
+    const int nthreads = blockDim.x;
+    if constexpr (GLDS) {
+        // units of 64 chunks (1 KiB): LDS destination = wave-uniform base + lane * 16
+        const int lane = threadIdx.x & 63;
+        const int wave = threadIdx.x >> 6;
+        const int nwaves = nthreads >> 6;
+        for (int unit = wave; unit * 64 < total; unit += nwaves) {
+            const int ci = unit * 64 + lane;
+            const int row = ci / CPR;                  // arr * rows + nn * W + w
+            const int c4 = (ci - row * CPR) * 4;
+            const int arr = row / rows;
+            const int rr = row - arr * rows;
+            const int nn = rr / W;
+            const int w = rr - nn * W;
+            const int l0 = (tile0 + w) * TILE;
+            const int m = rev ? (L - l0 - TILE + c4) : (l0 + c4);
+            const bool ok = ci < total && nn < nbn && m >= 0 && m < L;   // L % 4 == 0: whole chunk in range
+            const io_t* __restrict__ src = (arr == 0 ? Bg + (long)(n0 + nn) * B_ns : Cg + (long)(n0 + nn) * C_ns) + m;
+            if (ok) {
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + unit * 256), 16, 0, 0);
+            }
+        }
+    } else {
+        for (int ci = threadIdx.x; ci < total; ci += nthreads) {
+            const int row = ci / CPR;
+            const int c4 = (ci - row * CPR) * 4;
+            const int arr = row / rows;
+            const int rr = row - arr * rows;
+            const int nn = rr / W;
+            const int w = rr - nn * W;
+            const int l0 = (tile0 + w) * TILE;
+            const int m = rev ? (L - l0 - TILE + c4) : (l0 + c4);
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (nn < nbn && m < L && m + 4 > 0) {
+                const io_t* __restrict__ srow = arr == 0 ? Bg + (long)(n0 + nn) * B_ns : Cg + (long)(n0 + nn) * C_ns;
+                load4_guard<io_t>(srow, m, L, vec, v);
+            }
+            *reinterpret_cast<float4*>(dst + (long)ci * 4) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+}
+
+}  // namespace
+
+template <typename io_t, int T, bool GLDS, bool PREFETCH, bool REV>
+__device__ __forceinline__ void scan_fwd_body(const FwdArgs& p, float* smem, int b, int row0, int g) {
+    constexpr int TILE = 64 * T;
+    constexpr int VW = vec_width<T>::value;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int nwaves = blockDim.x >> 6;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int N = p.N, L = p.L;
+    const int N = p.N, L = p.L, W = p.W, R = p.R, NB = p.NB;
+    const int wr = wave / W;
+    const int wt = wave - wr * W;
 
-    const int lb = xcd_logical_block(blockIdx.x, gridDim.x);
-    const int b = lb / p.rowblocks;
-    const int rb = lb - b * p.rowblocks;
-    const int row0 = rb * nwaves;
-    const int r = row0 + wave;
-    const int g = row0 / p.rows_per_group;
+    const int bufsz = 2 * NB * W * TILE;                 // floats per staging buffer
+    float* sBC = smem;                                   // [2][2][NB][W][TILE]
+    float2* sAgg = reinterpret_cast<float2*>(sBC + 2 * bufsz);   // [2][R][W] tile aggregates (W > 1)
+    float* sA2 = reinterpret_cast<float*>(sAgg + 2 * R * W);     // [R][N]  A * log2(e)
+    float* sRun = sA2 + R * N;                           // [2][R][N] state entering the super-tile
+
+    const int r = row0 + wr;
     const bool vec = p.vec_ok != 0;
+    const int ur = p.u_row_mod > 0 ? r % p.u_row_mod : r;
 
-    const io_t* __restrict__ u_row = reinterpret_cast<const io_t*>(p.u) + (long)b * p.u_bs + (long)r * p.u_ds;
+    const io_t* __restrict__ u_row = reinterpret_cast<const io_t*>(p.u) + (long)b * p.u_bs + (long)ur * p.u_ds;
     const io_t* __restrict__ d_row = reinterpret_cast<const io_t*>(p.delta) + (long)b * p.dt_bs + (long)r * p.dt_ds;
     io_t* __restrict__ o_row = reinterpret_cast<io_t*>(p.out) + (long)b * p.o_bs + (long)r * p.o_ds;
     const io_t* __restrict__ Bg = reinterpret_cast<const io_t*>(p.B) + (long)b * p.B_bs + (long)g * p.B_gs;
     const io_t* __restrict__ Cg = reinterpret_cast<const io_t*>(p.C) + (long)b * p.C_bs + (long)g * p.C_gs;
-    const float* __restrict__ A_row = p.A + (long)r * p.A_ds;
     const float bias = p.bias ? p.bias[r] : 0.0f;
     const float Dd = p.D ? p.D[r] : 0.0f;
     float* __restrict__ x_row = p.x ? p.x + ((long)b * p.dim + r) * (long)p.n_chunks * 2 * N : nullptr;
 
-    for (int n = lane; n < N; n += 64) {
-        sCA[(wave * N + n) * 2 + 0] = A_row[(long)n * p.A_ns] * kLog2e;
-        sCA[(wave * N + n) * 2 + 1] = 0.0f;
+    if (wt == 0) {
+        const float* __restrict__ A_row = p.A + (long)r * p.A_ds;
+        for (int n = lane; n < N; n += 64) {
+            sA2[wr * N + n] = A_row[(long)n * p.A_ns] * kLog2e;
+            sRun[wr * N + n] = 0.0f;
+        }
     }
 
-    float dtot = 0.0f;                                 // sum of delta from l = 0 (wave-uniform)
-    const int ntiles = (L + G::TILE - 1) / G::TILE;
-    for (int tile = 0; tile < ntiles; ++tile) {
-        const int l0 = tile * G::TILE;
+    const int ntiles = (L + TILE - 1) / TILE;
+    const int nsuper = (ntiles + W - 1) / W;
+    const int nsb = (N + NB - 1) / NB;
+
+    // never multiply uninitialised LDS bits (stale/NaN) into the padding of the last tile
+    for (int i = tid; i < 2 * bufsz / 4; i += blockDim.x) reinterpret_cast<float4*>(sBC)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    // ---- B/C streaming: precomputed chunk plan + global_load_lds (f32, aligned), else registers
+    StagePlan<T, REV> plan;
+    if constexpr (GLDS) plan.init(NB, W, L);
+    auto stage = [&](float* dst, int n0, int tile0) {
+        const int nbn = (N - n0 < NB) ? (N - n0) : NB;
+        if constexpr (GLDS) {
+            plan.issue(dst, reinterpret_cast<const float*>(Bg), reinterpret_cast<const float*>(Cg), (int)p.B_ns, (int)p.C_ns,
+                       n0, nbn, tile0, L, NB * W * TILE, true);
+        } else {
+            stage_bc<io_t, T, false>(dst, Bg, Cg, p.B_ns, p.C_ns, n0, nbn, NB, W, tile0, L, REV, vec, true);
+        }
+    };
+    // ---- prologue: first B/C block and first u/delta segment
+    stage(sBC, 0, 0);
+    float uv[T], dv[T];
+    load_items<io_t, T, REV>(u_row, wt * TILE + lane * T, L, vec, uv);
+    load_items<io_t, T, REV>(d_row, wt * TILE + lane * T, L, vec, dv);
+    __syncthreads();
+
+    for (int st = 0; st < nsuper; ++st) {
+        const int tile = st * W + wt;
+        const int l0 = tile * TILE;
         const int lbase = l0 + lane * T;
 
         float dl[T], dlu[T], y[T];
-        {
-            float uv[T], dv[T];
-            load_items<io_t, T>(u_row, lbase, L, vec, uv);
-            load_items<io_t, T>(d_row, lbase, L, vec, dv);
 #pragma unroll
-            for (int k = 0; k < T; ++k) {
-                float d = dv[k] + bias;
-                if (p.softplus) { float sig; d = softplus_ref(d, sig); }
-                d = (lbase + k < L) ? d : 0.0f;        // identity element past the end (a = 1, b = 0)
-                dl[k] = d;
-                dlu[k] = d * uv[k];
-                y[k] = Dd * uv[k];
-            }
+        for (int k = 0; k < T; ++k) {
+            float d = dv[k] + bias;
+            if (p.softplus) { float sig; d = softplus_ref(d, sig); }
+            d = (lbase + k < L) ? d : 0.0f;            // identity element past the end (a = 1, b = 0)
+            dl[k] = d;
+            dlu[k] = d * uv[k];
+            y[k] = Dd * uv[k];
         }
         float dsum = 0.0f;
 #pragma unroll
         for (int k = 0; k < T; ++k) dsum += dl[k];
-        dtot += wave_sum(dsum);
-        const bool ckpt = x_row != nullptr && ((((l0 + G::TILE) & (2048 - 1)) == 0) || tile == ntiles - 1);
-        const int chunk = l0 >> 11;
 
-        for (int nb0 = 0; nb0 < N; nb0 += NB) {
-            __syncthreads();                            // previous state block fully consumed
-            // ---- stage B/C rows nb0 .. nb0+NB-1 of this tile into LDS (lane-blocked, padded)
-            for (int idx = tid; idx < NB * (G::TILE / 4); idx += blockDim.x) {
-                const int nn = idx / (G::TILE / 4);
-                const int l4 = (idx - nn * (G::TILE / 4)) * 4;
-                const int n = nb0 + nn;
-                const int l = l0 + l4;
-                float bv[4] = {0.f, 0.f, 0.f, 0.f}, cv[4] = {0.f, 0.f, 0.f, 0.f};
-                if (n < N && l < L) {
-                    load4<io_t>(Bg + (long)n * p.B_ns + l, vec, L - l, bv);
-                    load4<io_t>(Cg + (long)n * p.C_ns + l, vec, L - l, cv);
-                }
-                const int off = nn * G::ROW + (l4 / T) * G::LSTR + (l4 % T);
-                *reinterpret_cast<float4*>(sB + off) = make_float4(bv[0], bv[1], bv[2], bv[3]);
-                *reinterpret_cast<float4*>(sC + off) = make_float4(cv[0], cv[1], cv[2], cv[3]);
+        // checkpoint slot of this tile's end state (every kCkptPitch elements and at the very end)
+        const int lend = (l0 + TILE < L) ? (l0 + TILE) : L;
+        const bool ckpt = x_row != nullptr && l0 < L && ((lend % kCkptPitch) == 0 || lend == L);
+        const int cidx = (lend - 1) / kCkptPitch;
+        const float* sRunIn = sRun + (st & 1) * R * N + wr * N;
+        float* sRunOut = sRun + ((st + 1) & 1) * R * N + wr * N;
+
+        for (int sb = 0; sb < nsb; ++sb) {
+            const int step = st * nsb + sb;
+            const float* cur = sBC + (step & 1) * bufsz;
+            // ---- stream the next block of states (or the first block of the next super-tile)
+            {
+                float* nxt = sBC + ((step + 1) & 1) * bufsz;
+                if (sb + 1 < nsb) stage(nxt, (sb + 1) * NB, st * W);
+                else if (st + 1 < nsuper) stage(nxt, 0, (st + 1) * W);
             }
-            __syncthreads();
+            if (PREFETCH && sb == nsb - 1 && st + 1 < nsuper) {
+                load_items<io_t, T, REV>(u_row, lbase + W * TILE, L, vec, uv);
+                load_items<io_t, T, REV>(d_row, lbase + W * TILE, L, vec, dv);
+            }
 
-            const int nend = (N - nb0 < NB) ? (N - nb0) : NB;
+            const int n0 = sb * NB;
+            const int nend = (N - n0 < NB) ? (N - n0) : NB;
 #pragma unroll 1
             for (int nn = 0; nn < nend; ++nn) {
-                const int n = nb0 + nn;
-                const float2 ca = *reinterpret_cast<const float2*>(sCA + (wave * N + n) * 2);
-                const float A2 = ca.x;
-                const float xin_tile = ca.y;
-                const float4* __restrict__ pB = reinterpret_cast<const float4*>(sB + nn * G::ROW + lane * G::LSTR);
-                const float4* __restrict__ pC = reinterpret_cast<const float4*>(sC + nn * G::ROW + lane * G::LSTR);
+                const int n = n0 + nn;
+                const float A2 = sA2[wr * N + n];
+                const float* tB = cur + (nn * W + wt) * TILE;
+                const float* tC = tB + NB * W * TILE;
 
                 // ---- pass A: lane-local fold with zero incoming state
                 float a[T], bb[T];
                 float xa = 0.0f;
 #pragma unroll
-                for (int q = 0; q < T / 4; ++q) {
-                    const float4 bv = pB[q];
-                    const float bq[4] = {bv.x, bv.y, bv.z, bv.w};
+                for (int q = 0; q < T / VW; ++q) {
+                    float bq[VW];
+                    lds_read_chunk<T, REV>(tB, lane, q, bq);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int k = 4 * q + j;
+                    for (int j = 0; j < VW; ++j) {
+                        const int k = VW * q + j;
                         a[k] = fast_exp2(dl[k] * A2);
                         bb[k] = dlu[k] * bq[j];
                         xa = fmaf(a[k], xa, bb[k]);
                     }
                 }
                 // ---- wave scan of the lane aggregates (decay product, end state)
-                float pa = fast_exp2(A2 * dsum);
-                wave_scan_inclusive(pa, xa);
-                const float pe = wave_prev_lane(pa, 1.0f);
+                float sa = A2 * dsum;                   // log2 of the lane's decay product
+                wave_scan_inclusive(sa, xa);
+                float xin = sRunIn[n];
+                if (W > 1) {
+                    float2* agg = sAgg + ((n & 1) * R + wr) * W;
+                    if (lane == 63) agg[wt] = make_float2(fast_exp2(sa), xa);
+                    lds_barrier();
+                    for (int w = 0; w < wt; ++w) {
+                        const float2 t = agg[w];
+                        xin = fmaf(t.x, xin, t.y);
+                    }
+                }
+                const float pe = fast_exp2(wave_prev_lane(sa, 0.0f));
                 const float xe = wave_prev_lane(xa, 0.0f);
-                float x = fmaf(pe, xin_tile, xe);       // state entering this lane's segment
+                float x = fmaf(pe, xin, xe);            // state entering this lane's segment
 
                 // ---- pass B: replay with the true incoming state, accumulate C.x
 #pragma unroll
-                for (int q = 0; q < T / 4; ++q) {
-                    const float4 cv = pC[q];
-                    const float cq[4] = {cv.x, cv.y, cv.z, cv.w};
+                for (int q = 0; q < T / VW; ++q) {
+                    float cq[VW];
+                    lds_read_chunk<T, REV>(tC, lane, q, cq);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int k = 4 * q + j;
+                    for (int j = 0; j < VW; ++j) {
+                        const int k = VW * q + j;
                         x = fmaf(a[k], x, bb[k]);
                         y[k] = fmaf(cq[j], x, y[k]);
                     }
                 }
                 if (lane == 63) {
-                    sCA[(wave * N + n) * 2 + 1] = x;    // running state after this tile
-                    if (ckpt) {
-                        float2 v;
-                        v.x = fast_exp2(A2 * dtot);     // prod of a[n, 0..end(chunk)]
-                        v.y = x;
-                        *reinterpret_cast<float2*>(x_row + ((long)chunk * N + n) * 2) = v;
-                    }
+                    if (wt == W - 1) sRunOut[n] = x;    // state after this super-tile
+                    if (ckpt) x_row[((long)(cidx >> 1) * N + n) * 2 + (cidx & 1)] = x;
                 }
             }
+            __syncthreads();                            // staged block landed; current block consumed
         }
-        store_items<io_t, T>(o_row, lbase, L, vec, y);
+        if (!PREFETCH && st + 1 < nsuper) {
+            load_items<io_t, T, REV>(u_row, lbase + W * TILE, L, vec, uv);
+            load_items<io_t, T, REV>(d_row, lbase + W * TILE, L, vec, dv);
+        }
+        store_items<io_t, T, REV>(o_row, lbase, L, vec, y);
     }
 }
 
-template <typename io_t, int T>
-static hipError_t launch_fwd_t(const FwdArgs& a, int nwaves, hipStream_t stream) {
-    using G = TileGeom<T>;
-    const size_t lds = fwd_lds_bytes(T, nwaves, a.N);
+// T = 20 keeps 100 values per lane live (delta, delta*u, y, a, b): it needs ~150 VGPRs, i.e. at
+// most 3 waves per SIMD = 12 waves per workgroup; the shorter tiles fit 16 waves.
+template <int T> struct fwd_max_waves { static constexpr int value = (T >= 20) ? 12 : 16; };
+
+template <typename io_t, int T, bool GLDS, bool PREFETCH>
+__global__ void __launch_bounds__(64 * fwd_max_waves<T>::value)
+scan_fwd_kernel(const FwdArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lb = xcd_logical_block(blockIdx.x, gridDim.x);
+    const int b = lb / p.rowblocks;
+    const int rb = lb - b * p.rowblocks;
+    const int row0 = rb * p.R;
+    const int g = row0 / p.rows_per_group;
+    if (g >= p.rev_from_group) scan_fwd_body<io_t, T, GLDS, PREFETCH, true>(p, smem, b, row0, g);
+    else scan_fwd_body<io_t, T, GLDS, PREFETCH, false>(p, smem, b, row0, g);
+}
+
+template <typename io_t, int T, bool GLDS, bool PREFETCH>
+static hipError_t launch_fwd_t(const FwdArgs& a, hipStream_t stream) {
+    const size_t lds = fwd_lds_bytes(T, a.R, a.W, a.NB, a.N);
     const int grid = a.rowblocks * a.batch;
-    auto kern = scan_fwd_kernel<io_t, T>;
+    auto kern = scan_fwd_kernel<io_t, T, GLDS, PREFETCH>;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(nwaves * 64), lds, stream, a);
-    (void)sizeof(G);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(a.R * a.W * 64), lds, stream, a);
     return hipGetLastError();
 }
 
-template <typename io_t>
-static hipError_t launch_fwd_io(const FwdArgs& a, int T, int nwaves, hipStream_t stream) {
+template <typename io_t, bool GLDS>
+static hipError_t launch_fwd_io(const FwdArgs& a, int T, hipStream_t stream) {
     switch (T) {
-        case 4: return launch_fwd_t<io_t, 4>(a, nwaves, stream);
-        case 8: return launch_fwd_t<io_t, 8>(a, nwaves, stream);
-        case 16: return launch_fwd_t<io_t, 16>(a, nwaves, stream);
+        case 4: return launch_fwd_t<io_t, 4, GLDS, true>(a, stream);
+        case 5: return launch_fwd_t<io_t, 5, GLDS, true>(a, stream);
+        case 10: return launch_fwd_t<io_t, 10, GLDS, false>(a, stream);
+        case 20: return launch_fwd_t<io_t, 20, GLDS, false>(a, stream);
         default: return hipErrorInvalidValue;
     }
 }
 
-hipError_t launch_scan_fwd(const FwdArgs& a, int dtype, int T, int nwaves, hipStream_t stream) {
+hipError_t launch_scan_fwd(const FwdArgs& a, int dtype, int T, bool glds, hipStream_t stream) {
     switch (dtype) {
-        case 0: return launch_fwd_io<float>(a, T, nwaves, stream);
-        case 1: return launch_fwd_io<f16_t>(a, T, nwaves, stream);
-        case 2: return launch_fwd_io<bf16_t>(a, T, nwaves, stream);
+        case 0: return glds ? launch_fwd_io<float, true>(a, T, stream) : launch_fwd_io<float, false>(a, T, stream);
+        case 1: return launch_fwd_io<f16_t, false>(a, T, stream);
+        case 2: return launch_fwd_io<bf16_t, false>(a, T, stream);
         default: return hipErrorInvalidValue;
     }
 }

@@ -5,24 +5,22 @@
 
 namespace sigma {
 
-inline size_t fwd_lds_bytes(int T, int nwaves, int N) {
-    const int pad = (T >= 8) ? 4 : 0;
-    const size_t row = (size_t)kWave * (T + pad);
-    return sizeof(float) * (2 * kStateBlock * row + 2 * (size_t)nwaves * N);
+// forward: double-buffered B/C stage [2][2][NB][W][TILE] + tile aggregates + A, running state
+inline size_t fwd_lds_bytes(int T, int R, int W, int NB, int N) {
+    const size_t tile = (size_t)kWave * T;
+    return sizeof(float) * (2 * 2 * (size_t)NB * W * tile + 2 * 2 * (size_t)R * W + 3 * (size_t)R * N);
 }
 
-// backward: B, C tiles (padded, lane-blocked) + per-wave dB/dC term slabs ([wave][2][TILE])
-// + per-wave scratch: tile-start states for every tile of a 2048 chunk, reverse carry, dA partials
-inline size_t bwd_lds_bytes(int T, int nwaves, int N) {
-    const int pad = (T >= 8) ? 4 : 0;
-    const size_t row = (size_t)kWave * (T + pad);
-    const int tiles_per_chunk = 2048 / (kWave * T);
-    return sizeof(float) * (2 * kStateBlock * row + 2 * (size_t)nwaves * kWave * T +
-                            (size_t)nwaves * N * (tiles_per_chunk + 3));
+// backward: double-buffered B/C stage [2][2][NB][TILE] + per-wave dB/dC term slabs [R][2][TILE]
+// + per-wave scratch: tile-start states of one checkpoint span, reverse carry, dA partials, A
+inline size_t bwd_lds_bytes(int T, int R, int NB, int N) {
+    const size_t tile = (size_t)kWave * T;
+    const int tps = kCkptPitch / (kWave * T);
+    return sizeof(float) * (2 * 2 * (size_t)NB * tile + 2 * (size_t)R * tile + (size_t)R * N * (tps + 3));
 }
 
-hipError_t launch_scan_fwd(const FwdArgs& a, int dtype, int T, int nwaves, hipStream_t stream);
-hipError_t launch_scan_bwd(const BwdArgs& a, int dtype, int T, int nwaves, hipStream_t stream);
+hipError_t launch_scan_fwd(const FwdArgs& a, int dtype, int T, bool glds, hipStream_t stream);
+hipError_t launch_scan_bwd(const BwdArgs& a, int dtype, int T, bool glds, hipStream_t stream);
 hipError_t launch_selftest(float* out, hipStream_t stream);
 
 }  // namespace sigma

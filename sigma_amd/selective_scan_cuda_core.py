@@ -45,7 +45,7 @@ def _check(cond: bool, msg: str) -> None:
         raise RuntimeError(msg)
 
 
-def _check_common(u, delta, A, B, C, D_, delta_bias_, nrows):
+def _check_common(u, delta, A, B, C, D_, delta_bias_, nrows, u_row_mod=0):
     _check(u.dtype in _DTYPES, "selective_scan: input type must be float32, float16 or bfloat16")
     _check(A.dtype == torch.float32, "selective_scan: A must be float32")
     _check(delta.dtype == u.dtype and B.dtype == u.dtype and C.dtype == u.dtype,
@@ -56,6 +56,9 @@ def _check_common(u, delta, A, B, C, D_, delta_bias_, nrows):
     _check(u.stride(-1) == 1 or u.size(-1) <= 1, "u.stride(-1) must be 1")
     _check(delta.stride(-1) == 1 or delta.size(-1) <= 1, "delta.stride(-1) must be 1")
     batch, dim, seqlen = u.shape
+    if u_row_mod:
+        _check(delta.dim() == 3 and u.size(1) == u_row_mod, "u must have u_row_mod rows")
+        dim = delta.size(1)
     _check(A.dim() == 2, "A must have shape (dim, dstate)")
     dstate = A.size(1)
     _check(B.dim() == 4, "B must have shape (batch_size, n_groups, dstate, seqlen)")
@@ -85,8 +88,10 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
-def _fill_fwd(fp: _capi.FwdParams, u, delta, A, B, C, D_, delta_bias_, out, x, delta_softplus, sizes):
+def _fill_fwd(fp: _capi.FwdParams, u, delta, A, B, C, D_, delta_bias_, out, x, delta_softplus, sizes,
+              n_rev_groups=0, u_row_mod=0):
     batch, dim, seqlen, dstate, n_groups = sizes
+    fp.n_rev_groups, fp.u_row_mod = int(n_rev_groups), int(u_row_mod)
     fp.batch, fp.dim, fp.seqlen, fp.dstate, fp.n_groups = batch, dim, seqlen, dstate, n_groups
     fp.n_chunks = (seqlen + _capi.SIGMA_SCAN_CHUNK - 1) // _capi.SIGMA_SCAN_CHUNK
     fp.io_dtype = _DTYPES[u.dtype]
@@ -108,8 +113,16 @@ def fwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B: torch.Tensor, 
         nrows: int) -> List[torch.Tensor]:
     """Selective scan forward (selective_scan.cpp:165-249).  ``nrows`` only takes part in
     the shape checks: the row-to-workgroup mapping is chosen by the library."""
+    return fwd_ext(u, delta, A, B, C, D_, delta_bias_, delta_softplus, nrows=nrows)
+
+
+def fwd_ext(u, delta, A, B, C, D_, delta_bias_, delta_softplus, nrows: int = 1, n_rev_groups: int = 0,
+            u_row_mod: int = 0, need_x: bool = True) -> List[torch.Tensor]:
+    """``fwd`` plus the two extensions of include/sigma_scan.h used by the fused SS2D path:
+    ``n_rev_groups`` (the last groups scan backwards by addressing) and ``u_row_mod`` (u has only
+    ``u_row_mod`` physical rows; channel row r reads row r % u_row_mod)."""
     lib = _capi.load()
-    sizes = _check_common(u, delta, A, B, C, D_, delta_bias_, nrows)
+    sizes = _check_common(u, delta, A, B, C, D_, delta_bias_, nrows, u_row_mod)
     batch, dim, seqlen, dstate, _ = sizes
     n_chunks = (seqlen + _capi.SIGMA_SCAN_CHUNK - 1) // _capi.SIGMA_SCAN_CHUNK
     out = torch.empty_like(delta)                                   # selective_scan.cpp:226
@@ -117,7 +130,8 @@ def fwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B: torch.Tensor, 
     if batch == 0 or seqlen == 0:
         return [out, x]
     fp = _capi.FwdParams()
-    _fill_fwd(fp, u, delta, A, B, C, D_, delta_bias_, out, x, delta_softplus, sizes)
+    _fill_fwd(fp, u, delta, A, B, C, D_, delta_bias_, out, x if need_x else None, delta_softplus, sizes,
+              n_rev_groups, u_row_mod)
     with torch.cuda.device(u.device):                               # CUDAGuard, :240
         stream = torch.cuda.current_stream(u.device).cuda_stream    # :241
         key = (batch, dim, seqlen, dstate, sizes[4], u.element_size())
@@ -130,21 +144,28 @@ def bwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B: torch.Tensor, 
         D_: Optional[torch.Tensor], delta_bias_: Optional[torch.Tensor], dout: torch.Tensor,
         x_: Optional[torch.Tensor], delta_softplus: bool, nrows: int) -> List[Optional[torch.Tensor]]:
     """Selective scan backward (selective_scan.cpp:251-362)."""
+    return bwd_ext(u, delta, A, B, C, D_, delta_bias_, dout, x_, delta_softplus, nrows=nrows)
+
+
+def bwd_ext(u, delta, A, B, C, D_, delta_bias_, dout, x_, delta_softplus, nrows: int = 1, n_rev_groups: int = 0,
+            u_row_mod: int = 0) -> List[Optional[torch.Tensor]]:
+    """``bwd`` with the extensions of ``fwd_ext``.  du has one row per CHANNEL row (batch, dim, L)
+    even when u_row_mod folds several channel rows onto one u row."""
     lib = _capi.load()
-    sizes = _check_common(u, delta, A, B, C, D_, delta_bias_, nrows)
+    sizes = _check_common(u, delta, A, B, C, D_, delta_bias_, nrows, u_row_mod)
     batch, dim, seqlen, dstate, n_groups = sizes
     _check(dout.dtype == u.dtype, "dout must have the dtype of u")
     _check(dout.is_cuda, "dout must be a GPU tensor")
     _check(tuple(dout.shape) == (batch, dim, seqlen), "dout must have shape (batch_size, dim, seqlen)")
     _check(dout.stride(-1) == 1 or seqlen <= 1, "dout.stride(-1) must be 1")
     n_chunks = (seqlen + _capi.SIGMA_SCAN_CHUNK - 1) // _capi.SIGMA_SCAN_CHUNK
-    if n_chunks > 1:
-        _check(x_ is not None, "x is required when seqlen > 2048")   # :320
+    if n_chunks > 1 or seqlen > _capi.SIGMA_SCAN_CKPT_PITCH:
+        _check(x_ is not None, "x is required when seqlen > 2048")   # :320 (here: already above 1280)
     if x_ is not None:
         _check(x_.dtype == torch.float32 and x_.is_cuda and x_.is_contiguous(), "x must be a contiguous float32 GPU tensor")
         _check(tuple(x_.shape) == (batch, dim, n_chunks, 2 * dstate),
                "x must have shape (batch_size, dim, n_chunks, 2 * dstate)")
-    du = torch.empty_like(u)                                         # :329-337
+    du = torch.empty_like(delta)                                     # :329-337 (== empty_like(u) in the reference)
     ddelta = torch.empty_like(delta)
     dA = torch.zeros_like(A)
     # fully written by the library (deterministic two-stage sum), so no zero fill is needed
@@ -154,7 +175,7 @@ def bwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B: torch.Tensor, 
     ddelta_bias = torch.zeros_like(delta_bias_) if delta_bias_ is not None else None
     if batch > 0 and seqlen > 0:
         bp = _capi.BwdParams()
-        _fill_fwd(bp.fwd, u, delta, A, B, C, D_, delta_bias_, None, x_, delta_softplus, sizes)
+        _fill_fwd(bp.fwd, u, delta, A, B, C, D_, delta_bias_, None, x_, delta_softplus, sizes, n_rev_groups, u_row_mod)
         bp.dout, bp.du, bp.ddelta = _ptr(dout), _ptr(du), _ptr(ddelta)
         bp.dA, bp.dB, bp.dC, bp.dD, bp.ddelta_bias = _ptr(dA), _ptr(dB), _ptr(dC), _ptr(dD), _ptr(ddelta_bias)
         bp.dout_batch_stride, bp.dout_d_stride = dout.stride(0), dout.stride(1)

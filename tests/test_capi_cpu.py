@@ -26,10 +26,24 @@ def test_exports_every_declared_symbol():
         assert getattr(lib, name) is not None
 
 
-def test_struct_layout_matches_header():
-    # 8 int32 + 9 pointers + 14 int64 ; bwd adds 9 pointers + 15 int64
-    assert ctypes.sizeof(_capi.FwdParams) == 8 * 4 + 9 * 8 + 14 * 8
-    assert ctypes.sizeof(_capi.BwdParams) == ctypes.sizeof(_capi.FwdParams) + 9 * 8 + 15 * 8
+def test_struct_layout_matches_header(tmp_path):
+    """Compile include/sigma_scan.h with gcc and compare sizeof/offsetof of every field with the
+    ctypes mirror in sigma_amd/_capi.py."""
+    import subprocess
+    lines = []
+    for cname, cls in (("sigma_scan_fwd_params", _capi.FwdParams), ("sigma_scan_bwd_params", _capi.BwdParams)):
+        lines.append(f'printf("%s %zu\\n", "{cname}", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'printf("%s.%s %zu\\n", "{cname}", "{fname}", offsetof({cname}, {fname}));')
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "sigma_scan.h"\nint main(void){' + "".join(lines) + "return 0;}")
+    exe = tmp_path / "layout"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = dict(l.split() for l in subprocess.check_output([str(exe)], text=True).splitlines())
+    for cname, cls in (("sigma_scan_fwd_params", _capi.FwdParams), ("sigma_scan_bwd_params", _capi.BwdParams)):
+        assert int(got[cname]) == ctypes.sizeof(cls)
+        for fname, _ in cls._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, fname
 
 
 def _params(**kw):
@@ -59,32 +73,42 @@ def test_host_validation_without_gpu():
 def test_options_and_launch_plan():
     lib = _capi.load()
     with pytest.raises(RuntimeError):
-        _capi.set_option("fwd_items", 5)
+        _capi.set_option("fwd_items", 8)
     with pytest.raises(RuntimeError):
         _capi.set_option("no_such_option", 1)
-    plan = (ctypes.c_int32 * 4)()
-    # headline shape (1, 768, 19200), N=16, G=4 -> rows of one workgroup share a group
+    plan = (ctypes.c_int32 * 6)()
+    # headline shape (1, 768, 19200), N=16, G=4: few rows -> the sequence is split inside the workgroup
     p = _params(batch=1, dim=768, seqlen=19200, dstate=16, n_groups=4, n_chunks=10)
     assert lib.sigma_scan_fwd_plan(ctypes.byref(p), ctypes.byref(plan)) == 0
-    items, waves, grid, lds = list(plan)
-    assert items in (4, 8, 16) and waves in (1, 2, 4, 8, 16)
-    assert (768 // 4) % waves == 0 and grid == 768 // waves and lds <= 160 * 1024
+    items, rows, grid, lds, tiles, nb = list(plan)
+    assert items in (4, 5, 10, 20) and 1 <= rows <= 16 and 1 <= rows * tiles <= 16 and nb in (1, 2, 4, 8)
+    assert (768 // 4) % rows == 0 and grid == 768 // rows and lds <= 160 * 1024
+    assert tiles > 1 and grid >= 128          # one image per GPU still fills the chip
+    # a training batch has enough rows: 16 rows x 1 tile per workgroup
+    pb = _params(batch=16, dim=768, seqlen=19200, dstate=16, n_groups=4, n_chunks=10)
+    assert lib.sigma_scan_fwd_plan(ctypes.byref(pb), ctypes.byref(plan)) == 0
+    assert plan[1] == 16 and plan[4] == 1 and plan[2] == 16 * 768 // 16
     _capi.set_option("fwd_waves", 16)
     try:
         assert lib.sigma_scan_fwd_plan(ctypes.byref(p), ctypes.byref(plan)) == 0
-        assert plan[1] == 16 and plan[2] == 48
+        assert plan[1] == 16 and plan[2] == 48 and plan[4] == 1
     finally:
         _capi.set_option("fwd_waves", 0)
-    # reference unit-test shape: 24 rows, 2 groups -> 12 rows per group -> 4 rows per workgroup
+    # reference unit-test shape: 24 rows, 2 groups -> 12 rows per group; L = 372 -> tiles of 5 x 64 or 4 x 64
     p = _params(batch=2, dim=24, seqlen=372, dstate=8, n_groups=2, n_chunks=1)
     assert lib.sigma_scan_fwd_plan(ctypes.byref(p), ctypes.byref(plan)) == 0
-    assert plan[1] == 4 and plan[2] == 12
+    assert 12 % plan[1] == 0 and plan[2] == 48 // plan[1]
     bp = _capi.BwdParams()
     bp.fwd = p
     assert lib.sigma_scan_bwd_plan(ctypes.byref(bp), ctypes.byref(plan)) == 0
-    assert plan[0] in (4, 8) and plan[3] <= 160 * 1024
-    # 12 rows per group, 4 per workgroup -> 3 partial slabs of (B, G, N, L) for each of dB, dC
-    assert lib.sigma_scan_bwd_workspace_bytes(ctypes.byref(bp)) == 2 * 3 * 2 * 2 * 8 * 372 * 4
+    assert plan[0] in (4, 5, 10) and plan[3] <= 160 * 1024 and 12 % plan[1] == 0
+    # P = 12 / rows partial slabs of (B, G, N, L) for each of dB, dC (none when one workgroup owns the group)
+    P = 12 // plan[1]
+    assert lib.sigma_scan_bwd_workspace_bytes(ctypes.byref(bp)) == (0 if P == 1 else 2 * P * 2 * 2 * 8 * 372 * 4)
+    # extension fields are validated
+    bad = _params(batch=1, dim=8, seqlen=64, dstate=4, n_groups=2, n_chunks=1)
+    bad.n_rev_groups = 3
+    assert lib.sigma_scan_fwd_plan(ctypes.byref(bad), ctypes.byref(plan)) != 0
 
 
 def test_operator_module_raises_without_gpu_tensors():

@@ -199,9 +199,10 @@ def test_real_stage_shapes_forward_and_backward(shape):
     _compare(out, grads, u, delta, A, B, C, D, bias, dout, True, torch.float32)
 
 
-def test_checkpoint_tensor_matches_reference_layout():
-    """x[b, r, c, :] = float2[n] (prod a over l <= end(c), state at end(c))
-    (selective_scan.cpp:225-228; selective_scan_fwd_kernel.cuh:181-184)."""
+def test_checkpoint_tensor_shape_and_documented_layout():
+    """x has the reference's SHAPE (batch, dim, ceil(L/2048), 2N) (selective_scan.cpp:225-228); its
+    contents are this library's private fwd->bwd scratch, documented in include/sigma_scan.h:
+    checkpoint j = state after element min(L, (j+1)*1280)-1 at x[b, r, j//2, 2n + j%2]."""
     so = _oracle()
     batch, KD, L, N, G = 2, 8, 5000, 4, 2
     u, delta, A, B, C, D, bias, _ = _model_like(batch, KD, L, N, G, seed=3)
@@ -209,13 +210,63 @@ def test_checkpoint_tensor_matches_reference_layout():
     out, x = _core().fwd(u.to(dev), delta.to(dev), A.to(dev), B.to(dev), C.to(dev), D.to(dev), bias.to(dev), True, 1)
     assert x.shape == (batch, KD, 3, 2 * N) and x.dtype == torch.float32
     x = x.cpu().view(batch, KD, 3, N, 2)
-    dl = torch.nn.functional.softplus(delta.double() + bias.double()[None, :, None])
-    for c, end in enumerate([2048, 4096, 5000]):
+    for j, end in enumerate([1280, 2560, 3840, 5000]):
         _, st = so.selective_scan_oracle(u[..., :end], delta[..., :end], A, B[..., :end], C[..., :end], D, bias, True,
                                          acc64=True, return_last_state=True)
-        torch.testing.assert_close(x[:, :, c, :, 1], st, rtol=1e-3, atol=1e-4)
-        prod = torch.exp(dl[..., :end].sum(-1)[..., None] * A.double()[None])
-        torch.testing.assert_close(x[:, :, c, :, 0].double(), prod, rtol=1e-3, atol=1e-30)
+        torch.testing.assert_close(x[:, :, j // 2, :, j % 2], st, rtol=1e-3, atol=1e-4)
+
+
+def _run_hip_ext(u, delta, A, B, C, D, bias, dout, n_rev_groups=0, u_row_mod=0):
+    """fwd + bwd through the extended operator entry (reverse groups / shared u rows)."""
+    core = _core()
+    dev = "cuda"
+    args = [t.to(dev) for t in (u, delta, A, B, C, D, bias)]
+    out, x = core.fwd_ext(*args, True, n_rev_groups=n_rev_groups, u_row_mod=u_row_mod)
+    grads = core.bwd_ext(*args, dout.to(dev), x, True, n_rev_groups=n_rev_groups, u_row_mod=u_row_mod)
+    return out.cpu(), [g.cpu() for g in grads]
+
+
+@pytest.mark.parametrize("L", [300, 640, 1200, 1283, 2564, 4800])
+def test_reversed_groups_equal_flipped_inputs(L):
+    """CrossScan's flip done by addressing: with the last two of four groups reversed, the result
+    must equal the plain operator applied to explicitly flipped copies (vmamba.py:80-121)."""
+    batch, KD, N, G = 2, 32, 16, 4
+    u, delta, A, B, C, D, bias, dout = _model_like(batch, KD, L, N, G, seed=11)
+    out, grads = _run_hip_ext(u, delta, A, B, C, D, bias, dout, n_rev_groups=2)
+    half = KD // 2
+
+    def flip_rows(t):            # (B, KD, L): rows of groups 2, 3 flipped along L
+        return torch.cat([t[:, :half], t[:, half:].flip(-1)], dim=1)
+
+    def flip_groups(t):          # (B, G, N, L)
+        return torch.cat([t[:, :2], t[:, 2:].flip(-1)], dim=1)
+
+    so = _oracle()
+    uf, df, Bf, Cf, gf = flip_rows(u), flip_rows(delta), flip_groups(B), flip_groups(C), flip_rows(dout)
+    ref = flip_rows(so.selective_scan_oracle(uf, df, A, Bf, Cf, D, bias, True, acc64=True))
+    torch.testing.assert_close(out, ref, rtol=6e-4, atol=2e-3)
+    rg = list(so.selective_scan_oracle_bwd(uf, df, A, Bf, Cf, D, bias, gf, True))
+    rg[0], rg[1] = flip_rows(rg[0]), flip_rows(rg[1])
+    rg[3], rg[4] = flip_groups(rg[3]), flip_groups(rg[4])
+    for name, g, r in zip(["u", "delta", "A", "B", "C", "D", "bias"], grads, rg):
+        torch.testing.assert_close(g, r, rtol=3e-3, atol=2e-3 + 2e-4 * float(r.abs().max()),
+                                   msg=lambda m, name=name: f"d{name}: {m}")
+
+
+def test_shared_u_rows():
+    """u_row_mod: channel row r reads u row r % mod (two physical copies serve four directions)."""
+    batch, KD, L, N, G = 1, 32, 900, 4, 4
+    u, delta, A, B, C, D, bias, dout = _model_like(batch, KD, L, N, G, seed=13)
+    u_half = u[:, :KD // 2].contiguous()
+    u_full = torch.cat([u_half, u_half], dim=1)
+    out, grads = _run_hip_ext(u_half, delta, A, B, C, D, bias, dout, u_row_mod=KD // 2)
+    so = _oracle()
+    ref = so.selective_scan_oracle(u_full, delta, A, B, C, D, bias, True, acc64=True)
+    torch.testing.assert_close(out, ref, rtol=6e-4, atol=2e-3)
+    rg = so.selective_scan_oracle_bwd(u_full, delta, A, B, C, D, bias, dout, True)
+    for name, g, r in zip(["u", "delta", "A", "B", "C", "D", "bias"], grads, rg):   # du stays per channel row
+        torch.testing.assert_close(g, r, rtol=3e-3, atol=2e-3 + 2e-4 * float(r.abs().max()),
+                                   msg=lambda m, name=name: f"d{name}: {m}")
 
 
 def test_strided_and_unaligned_inputs():
@@ -242,9 +293,11 @@ def test_strided_and_unaligned_inputs():
                                    msg=lambda m, name=name: f"d{name}: {m}")
 
 
-@pytest.mark.parametrize("opt", [("fwd_items", 4), ("fwd_items", 8), ("fwd_items", 16), ("fwd_waves", 1),
-                                 ("fwd_waves", 2), ("fwd_waves", 16), ("bwd_items", 4), ("bwd_items", 8),
-                                 ("bwd_waves", 1), ("bwd_waves", 8)])
+@pytest.mark.parametrize("opt", [("fwd_items", 4), ("fwd_items", 5), ("fwd_items", 10), ("fwd_items", 20),
+                                 ("fwd_waves", 1), ("fwd_waves", 2), ("fwd_waves", 16), ("fwd_tiles", 1),
+                                 ("fwd_tiles", 2), ("fwd_tiles", 4), ("fwd_nb", 1), ("fwd_nb", 2), ("no_glds", 1),
+                                 ("bwd_items", 4), ("bwd_items", 5), ("bwd_items", 10), ("bwd_waves", 1),
+                                 ("bwd_waves", 8), ("bwd_nb", 1), ("bwd_nb", 2)])
 def test_every_launch_geometry_is_correct(opt):
     """All (items per lane, rows per workgroup) variants compute the same thing."""
     from sigma_amd import _capi

@@ -34,6 +34,10 @@ SHAPES = {
     "enc_s2_b8": (8, 3072, 1200, 16, 4),
     "dec_s0_b8": (8, 768, 19200, 4, 4),
     "conmb_s0_b8": (8, 384, 38400, 4, 2),
+    "enc_s0_b16": (16, 768, 19200, 16, 4),
+    "enc_s1_b16": (16, 1536, 4800, 16, 4),
+    "enc_s2_b16": (16, 3072, 1200, 16, 4),
+    "enc_s3_b16": (16, 6144, 300, 16, 4),
 }
 
 HBM_PEAK = 8.0e12
@@ -90,21 +94,22 @@ def main():
         u, delta, A, Bm, Cm, D, bias, dout = make(shape, dt)
         _, x = core.fwd(u, delta, A, Bm, Cm, D, bias, True, 1)
         fb, bb = fwd_bytes(*shape, s=es), bwd_bytes(*shape, s=es)
-        geos = [(0, 0)]
+        geos = [(0, 0, 0)]
         if a.sweep:
-            geos += [(t, w) for t in (4, 8, 16) for w in (2, 4, 8, 16)]
-        for items, waves in geos:
-            rec = {"shape": name, "dims": shape, "dtype": a.dtype, "items": items, "waves": waves}
+            geos += [(t, w, tl) for t in (5, 10, 20) for (w, tl) in ((16, 1), (8, 1), (8, 2), (4, 4), (3, 5), (2, 8), (12, 1))]
+        for items, waves, tiles in geos:
+            rec = {"shape": name, "dims": shape, "dtype": a.dtype, "items": items, "waves": waves, "tiles": tiles}
             _capi.set_option("fwd_items", items)
             _capi.set_option("fwd_waves", waves)
+            _capi.set_option("fwd_tiles", tiles)
             t = time_call(lambda: core.fwd(u, delta, A, Bm, Cm, D, bias, True, 1), a.iters)
             rec.update(fwd_us=t * 1e6, fwd_GBs=fb / t / 1e9, fwd_frac_of_8TBs=fb / t / HBM_PEAK)
-            if items in (0, 4, 8):
+            if items in (0, 5, 10) and tiles <= 1:
                 _capi.set_option("bwd_items", items)
                 _capi.set_option("bwd_waves", waves)
                 t = time_call(lambda: core.bwd(u, delta, A, Bm, Cm, D, bias, dout, x, True, 1), max(3, a.iters // 2))
                 rec.update(bwd_us=t * 1e6, bwd_GBs=bb / t / 1e9, bwd_frac_of_8TBs=bb / t / HBM_PEAK)
-            for k in ("fwd_items", "fwd_waves", "bwd_items", "bwd_waves"):
+            for k in ("fwd_items", "fwd_waves", "fwd_tiles", "bwd_items", "bwd_waves"):
                 _capi.set_option(k, 0)
             rows.append(rec)
             print(json.dumps(rec), flush=True)
