@@ -79,14 +79,15 @@ typedef struct sigma_scan_fwd_params {
     int32_t io_dtype;   /* enum sigma_dtype */
     int32_t delta_softplus;
     /* Extensions for the fused SS2D caller (both 0 = the reference operator):
-     *  n_rev_groups: the LAST n_rev_groups groups scan the sequence backwards -- every
-     *      sequence operand of their rows (u, delta, B, C, out, dout, du, ddelta, dB, dC) is
-     *      read / written at index seqlen-1-l.  This is CrossScan's flip (vmamba.py:80-98,
-     *      directions 2 and 3) done by addressing instead of by materialised copies.
-     *  u_row_mod: when > 0, channel row r reads u row (r % u_row_mod): the four CrossScan
-     *      directions share two physical copies of x (row-major, column-major). */
-    int32_t n_rev_groups;
-    int32_t u_row_mod;
+     *  rev_group_mask: bit g set -> group g scans the sequence backwards: every sequence operand
+     *      of its rows (u, delta, B, C, out, dout, du, ddelta, dB, dC) is read / written at index
+     *      seqlen-1-l.  This is CrossScan's flip (vmamba.py:80-98, directions 2 and 3) done by
+     *      addressing instead of by materialised copies.  Needs n_groups <= 32 when non-zero.
+     *  u_group_shift: the rows of group g read the u rows of group (g >> u_group_shift), i.e. u
+     *      has shape (B, dim >> u_group_shift, L): CrossScan directions that differ only by the
+     *      flip share one physical copy of x. */
+    uint32_t rev_group_mask;
+    int32_t u_group_shift;
     /* inputs */
     const void *u;            /* (B, dim, L)        io_dtype */
     const void *delta;        /* (B, dim, L)        io_dtype */
@@ -112,7 +113,7 @@ typedef struct sigma_scan_bwd_params {
     sigma_scan_fwd_params fwd;   /* out is unused; x is the tensor saved by fwd (the reference
                                     requires it when n_chunks > 1, selective_scan.cpp:320; here it
                                     may be NULL only when seqlen <= SIGMA_SCAN_CKPT_PITCH) */
-    const void *dout;            /* (B, dim, L)   io_dtype */
+    const void *dout;            /* (B, dim >> dout_group_shift, L)   io_dtype */
     void *du;                    /* (B, dim, L)   io_dtype, fully written */
     void *ddelta;                /* (B, dim, L)   io_dtype, fully written */
     float *dA;                   /* (dim, N)      f32, ACCUMULATED into (caller zeroes, :331) */
@@ -127,6 +128,9 @@ typedef struct sigma_scan_bwd_params {
                                     after the call.  Provided by the caller because the callee
                                     never allocates. */
     int64_t workspace_bytes;
+    int32_t dout_group_shift;    /* like u_group_shift for dout: CrossMerge's adjoint hands the same
+                                    gradient to the directions that share a memory order */
+    int32_t reserved_;
     int64_t dout_batch_stride, dout_d_stride;
     int64_t du_batch_stride, du_d_stride;
     int64_t ddelta_batch_stride, ddelta_d_stride;

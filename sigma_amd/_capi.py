@@ -31,7 +31,7 @@ class FwdParams(ctypes.Structure):
         ("batch", ctypes.c_int32), ("dim", ctypes.c_int32), ("seqlen", ctypes.c_int32),
         ("dstate", ctypes.c_int32), ("n_groups", ctypes.c_int32), ("n_chunks", ctypes.c_int32),
         ("io_dtype", ctypes.c_int32), ("delta_softplus", ctypes.c_int32),
-        ("n_rev_groups", ctypes.c_int32), ("u_row_mod", ctypes.c_int32),
+        ("rev_group_mask", ctypes.c_uint32), ("u_group_shift", ctypes.c_int32),
         ("u", ctypes.c_void_p), ("delta", ctypes.c_void_p), ("A", ctypes.c_void_p),
         ("B", ctypes.c_void_p), ("C", ctypes.c_void_p), ("D", ctypes.c_void_p),
         ("delta_bias", ctypes.c_void_p),
@@ -52,6 +52,7 @@ class BwdParams(ctypes.Structure):
         ("dA", ctypes.c_void_p), ("dB", ctypes.c_void_p), ("dC", ctypes.c_void_p),
         ("dD", ctypes.c_void_p), ("ddelta_bias", ctypes.c_void_p),
         ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_int64),
+        ("dout_group_shift", ctypes.c_int32), ("reserved_", ctypes.c_int32),
         ("dout_batch_stride", ctypes.c_int64), ("dout_d_stride", ctypes.c_int64),
         ("du_batch_stride", ctypes.c_int64), ("du_d_stride", ctypes.c_int64),
         ("ddelta_batch_stride", ctypes.c_int64), ("ddelta_d_stride", ctypes.c_int64),

@@ -50,10 +50,10 @@ int check_fwd(const sigma_scan_fwd_params* p, bool need_out, bool need_ptrs = tr
     if (p->n_chunks != (p->seqlen + SIGMA_SCAN_CHUNK - 1) / SIGMA_SCAN_CHUNK)
         return fail(SIGMA_ERR_BAD_SHAPE, "n_chunks must be ceil(seqlen/2048) (got %d for seqlen %d)", p->n_chunks,
                     p->seqlen);
-    if (p->n_rev_groups < 0 || p->n_rev_groups > p->n_groups)
-        return fail(SIGMA_ERR_BAD_SHAPE, "n_rev_groups must be in [0, n_groups] (got %d)", p->n_rev_groups);
-    if (p->u_row_mod < 0 || p->u_row_mod > p->dim)
-        return fail(SIGMA_ERR_BAD_SHAPE, "u_row_mod must be in [0, dim] (got %d)", p->u_row_mod);
+    if (p->rev_group_mask != 0 && (p->n_groups > 32 || (p->n_groups < 32 && (p->rev_group_mask >> p->n_groups) != 0)))
+        return fail(SIGMA_ERR_BAD_SHAPE, "rev_group_mask 0x%x names groups >= n_groups (%d)", p->rev_group_mask, p->n_groups);
+    if (p->u_group_shift < 0 || p->u_group_shift > 5)
+        return fail(SIGMA_ERR_BAD_SHAPE, "u_group_shift must be in [0, 5] (got %d)", p->u_group_shift);
     if (p->batch == 0 || p->seqlen == 0 || !need_ptrs) return SIGMA_OK;
     if (!p->u || !p->delta || !p->A || !p->B || !p->C || (need_out && !p->out))
         return fail(SIGMA_ERR_NULL_ARG, "u/delta/A/B/C/out must be non-NULL device pointers");
@@ -81,8 +81,8 @@ sigma::FwdArgs make_fwd_args(const sigma_scan_fwd_params* p, int R, int W, int N
     a.n_chunks = p->n_chunks; a.rows_per_group = p->dim / p->n_groups; a.softplus = p->delta_softplus ? 1 : 0;
     a.vec_ok = vec ? 1 : 0; a.rowblocks = p->dim / R;
     a.R = R; a.W = W; a.NB = NB;
-    a.rev_from_group = p->n_groups - p->n_rev_groups;
-    a.u_row_mod = p->u_row_mod;
+    a.rev_mask = p->rev_group_mask;
+    a.u_gshift = p->u_group_shift;
     a.u_bs = p->u_batch_stride; a.u_ds = p->u_d_stride; a.dt_bs = p->delta_batch_stride; a.dt_ds = p->delta_d_stride;
     a.A_ds = p->A_d_stride; a.A_ns = p->A_dstate_stride;
     a.B_bs = p->B_batch_stride; a.B_gs = p->B_group_stride; a.B_ns = p->B_dstate_stride;
@@ -270,7 +270,7 @@ int sigma_selective_scan_fwd(const sigma_scan_fwd_params* p, void* stream) {
     int rc = check_fwd(p, true);
     if (rc) return rc;
     if (p->batch == 0 || p->seqlen == 0) return SIGMA_OK;
-    const bool vec = vec_ok_fwd(p, true) && (p->n_rev_groups == 0 || p->seqlen % 4 == 0);
+    const bool vec = vec_ok_fwd(p, true) && (p->rev_group_mask == 0 || p->seqlen % 4 == 0);
     const Plan pl = plan_fwd(p, vec);
     if (pl.lds > kLdsLimit) return fail(SIGMA_ERR_BAD_SHAPE, "LDS budget exceeded (%zu B)", pl.lds);
     const sigma::FwdArgs a = make_fwd_args(p, pl.rows, pl.tiles, pl.nb, vec);
@@ -286,7 +286,7 @@ bool vec_ok_bwd(const sigma_scan_bwd_params* q) {
     return vec_ok_fwd(p, false) && aligned_to(q->dout, al) && aligned_to(q->du, al) && aligned_to(q->ddelta, al) &&
            q->dout_batch_stride % 4 == 0 && q->dout_d_stride % 4 == 0 && q->du_batch_stride % 4 == 0 &&
            q->du_d_stride % 4 == 0 && q->ddelta_batch_stride % 4 == 0 && q->ddelta_d_stride % 4 == 0 &&
-           (p->n_rev_groups == 0 || p->seqlen % 4 == 0);
+           (p->rev_group_mask == 0 || p->seqlen % 4 == 0);
 }
 }  // namespace
 
@@ -335,7 +335,10 @@ int sigma_selective_scan_bwd(const sigma_scan_bwd_params* q, void* stream) {
     a.dA_ds = q->dA_d_stride; a.dA_ns = q->dA_dstate_stride;
     a.dB_bs = q->dB_batch_stride; a.dB_gs = q->dB_group_stride; a.dB_ns = q->dB_dstate_stride;
     a.dC_bs = q->dC_batch_stride; a.dC_gs = q->dC_group_stride; a.dC_ns = q->dC_dstate_stride;
+    if (q->dout_group_shift < 0 || q->dout_group_shift > 5)
+        return fail(SIGMA_ERR_BAD_SHAPE, "dout_group_shift must be in [0, 5] (got %d)", q->dout_group_shift);
     a.P = P;
+    a.g_gshift = q->dout_group_shift;
     a.out_vec_ok = (aligned_to(q->dB, 16) && aligned_to(q->dC, 16) && q->dB_batch_stride % 4 == 0 &&
                     q->dB_group_stride % 4 == 0 && q->dB_dstate_stride % 4 == 0 && q->dC_batch_stride % 4 == 0 &&
                     q->dC_group_stride % 4 == 0 && q->dC_dstate_stride % 4 == 0) ? 1 : 0;

@@ -94,11 +94,12 @@ __device__ __forceinline__ void scan_bwd_body(const BwdArgs& q, float* smem, int
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = row0 + wave;
     const bool vec = p.vec_ok != 0;
-    const int ur = p.u_row_mod > 0 ? r % p.u_row_mod : r;
+    const int ur = r - ((g - (g >> p.u_gshift)) * p.rows_per_group);   // same row of group g >> u_gshift
 
     const io_t* __restrict__ u_row = reinterpret_cast<const io_t*>(p.u) + (long)b * p.u_bs + (long)ur * p.u_ds;
     const io_t* __restrict__ d_row = reinterpret_cast<const io_t*>(p.delta) + (long)b * p.dt_bs + (long)r * p.dt_ds;
-    const io_t* __restrict__ g_row = reinterpret_cast<const io_t*>(q.dout) + (long)b * q.g_bs + (long)r * q.g_ds;
+    const int gr = r - ((g - (g >> q.g_gshift)) * p.rows_per_group);
+    const io_t* __restrict__ g_row = reinterpret_cast<const io_t*>(q.dout) + (long)b * q.g_bs + (long)gr * q.g_ds;
     io_t* __restrict__ du_row = reinterpret_cast<io_t*>(q.du) + (long)b * q.du_bs + (long)r * q.du_ds;
     io_t* __restrict__ dd_row = reinterpret_cast<io_t*>(q.ddelta) + (long)b * q.dd_bs + (long)r * q.dd_ds;
     const io_t* __restrict__ Bg = reinterpret_cast<const io_t*>(p.B) + (long)b * p.B_bs + (long)g * p.B_gs;
@@ -416,7 +417,7 @@ scan_bwd_kernel(const BwdArgs q) {
     const int rb = lb - b * q.f.rowblocks;
     const int row0 = rb * R;
     const int g = row0 / q.f.rows_per_group;
-    if (g >= q.f.rev_from_group) scan_bwd_body<io_t, T, GLDS, true>(q, smem, b, row0, g);
+    if ((q.f.rev_mask >> g) & 1u) scan_bwd_body<io_t, T, GLDS, true>(q, smem, b, row0, g);
     else scan_bwd_body<io_t, T, GLDS, false>(q, smem, b, row0, g);
 }
 

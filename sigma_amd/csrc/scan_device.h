@@ -384,8 +384,8 @@ struct FwdArgs {
     int R;                // rows per workgroup
     int W;                // consecutive tiles per workgroup ("super-tile"); waves = R * W
     int NB;               // states staged per step
-    int rev_from_group;   // groups g >= this run over the sequence in reverse memory order (>= G: none)
-    int u_row_mod;        // > 0: u row of channel row r is r % u_row_mod (CrossScan without the 4x copy)
+    unsigned rev_mask;    // bit g set: group g runs over the sequence in reverse memory order
+    int u_gshift;         // u rows of group g are those of group (g >> u_gshift): directions share copies of x
     long u_bs, u_ds, dt_bs, dt_ds, A_ds, A_ns;
     long B_bs, B_gs, B_ns, C_bs, C_gs, C_ns, o_bs, o_ds;
 };
@@ -397,6 +397,7 @@ struct BwdArgs {
     float* ws_dB; float* ws_dC;     // [P][batch][G][N][L] per-workgroup partials (P > 1)
     int P;                          // workgroups per (batch, group) = rows_per_group / R
     int out_vec_ok;                 // dB/dC rows are 16-byte aligned
+    int g_gshift;                   // dout rows of group g are those of group (g >> g_gshift)
     long g_bs, g_ds, du_bs, du_ds, dd_bs, dd_ds, dA_ds, dA_ns;
     long dB_bs, dB_gs, dB_ns, dC_bs, dC_gs, dC_ns;
 };

@@ -106,7 +106,7 @@ __device__ __forceinline__ void scan_fwd_body(const FwdArgs& p, float* smem, int
 
     const int r = row0 + wr;
     const bool vec = p.vec_ok != 0;
-    const int ur = p.u_row_mod > 0 ? r % p.u_row_mod : r;
+    const int ur = r - ((g - (g >> p.u_gshift)) * p.rows_per_group);   // same row of group g >> u_gshift
 
     const io_t* __restrict__ u_row = reinterpret_cast<const io_t*>(p.u) + (long)b * p.u_bs + (long)ur * p.u_ds;
     const io_t* __restrict__ d_row = reinterpret_cast<const io_t*>(p.delta) + (long)b * p.dt_bs + (long)r * p.dt_ds;
@@ -272,7 +272,7 @@ scan_fwd_kernel(const FwdArgs p) {
     const int rb = lb - b * p.rowblocks;
     const int row0 = rb * p.R;
     const int g = row0 / p.rows_per_group;
-    if (g >= p.rev_from_group) scan_fwd_body<io_t, T, GLDS, PREFETCH, true>(p, smem, b, row0, g);
+    if ((p.rev_mask >> g) & 1u) scan_fwd_body<io_t, T, GLDS, PREFETCH, true>(p, smem, b, row0, g);
     else scan_fwd_body<io_t, T, GLDS, PREFETCH, false>(p, smem, b, row0, g);
 }
 

@@ -28,7 +28,14 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+import os
+
 from ...selective_scan import selective_scan_fn
+from ...ss2d_fused import ss2d_core
+
+# SIGMA_SS2D_FUSED=0 selects the plain-autograd formulation of SS2D's core (A/B measurements and
+# the fused-vs-unfused parity test); both run the same HIP scan kernels.
+_FUSED_SS2D = os.environ.get("SIGMA_SS2D_FUSED", "1") != "0"
 
 
 # --------------------------------------------------------------------------- small helpers
@@ -128,6 +135,9 @@ def ss2d_scan(x: torch.Tensor, x_proj_weight, dt_projs_weight, dt_projs_bias, A_
       k=0 row-major, k=1 column-major, k=2 reversed row-major, k=3 reversed column-major.
     """
     B, d, H, W = x.shape
+    if _FUSED_SS2D:
+        y = ss2d_core(x, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds)     # (B, d, L)
+        return out_norm(y.transpose(1, 2).reshape(B, H, W, d)).to(x.dtype)
     K, c, _ = x_proj_weight.shape                # c = R + 2N
     R = dt_projs_weight.shape[2]
     N = A_logs.shape[1]

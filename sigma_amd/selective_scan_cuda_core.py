@@ -45,7 +45,7 @@ def _check(cond: bool, msg: str) -> None:
         raise RuntimeError(msg)
 
 
-def _check_common(u, delta, A, B, C, D_, delta_bias_, nrows, u_row_mod=0):
+def _check_common(u, delta, A, B, C, D_, delta_bias_, nrows, u_gshift=0):
     _check(u.dtype in _DTYPES, "selective_scan: input type must be float32, float16 or bfloat16")
     _check(A.dtype == torch.float32, "selective_scan: A must be float32")
     _check(delta.dtype == u.dtype and B.dtype == u.dtype and C.dtype == u.dtype,
@@ -56,8 +56,9 @@ def _check_common(u, delta, A, B, C, D_, delta_bias_, nrows, u_row_mod=0):
     _check(u.stride(-1) == 1 or u.size(-1) <= 1, "u.stride(-1) must be 1")
     _check(delta.stride(-1) == 1 or delta.size(-1) <= 1, "delta.stride(-1) must be 1")
     batch, dim, seqlen = u.shape
-    if u_row_mod:
-        _check(delta.dim() == 3 and u.size(1) == u_row_mod, "u must have u_row_mod rows")
+    if u_gshift:
+        _check(delta.dim() == 3 and B.dim() == 4 and B.size(1) % (1 << u_gshift) == 0
+               and u.size(1) * (1 << u_gshift) == delta.size(1), "u must have dim >> u_gshift rows")
         dim = delta.size(1)
     _check(A.dim() == 2, "A must have shape (dim, dstate)")
     dstate = A.size(1)
@@ -89,9 +90,9 @@ def _ptr(t: Optional[torch.Tensor]):
 
 
 def _fill_fwd(fp: _capi.FwdParams, u, delta, A, B, C, D_, delta_bias_, out, x, delta_softplus, sizes,
-              n_rev_groups=0, u_row_mod=0):
+              rev_mask=0, u_gshift=0):
     batch, dim, seqlen, dstate, n_groups = sizes
-    fp.n_rev_groups, fp.u_row_mod = int(n_rev_groups), int(u_row_mod)
+    fp.rev_group_mask, fp.u_group_shift = int(rev_mask), int(u_gshift)
     fp.batch, fp.dim, fp.seqlen, fp.dstate, fp.n_groups = batch, dim, seqlen, dstate, n_groups
     fp.n_chunks = (seqlen + _capi.SIGMA_SCAN_CHUNK - 1) // _capi.SIGMA_SCAN_CHUNK
     fp.io_dtype = _DTYPES[u.dtype]
@@ -116,13 +117,13 @@ def fwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B: torch.Tensor, 
     return fwd_ext(u, delta, A, B, C, D_, delta_bias_, delta_softplus, nrows=nrows)
 
 
-def fwd_ext(u, delta, A, B, C, D_, delta_bias_, delta_softplus, nrows: int = 1, n_rev_groups: int = 0,
-            u_row_mod: int = 0, need_x: bool = True) -> List[torch.Tensor]:
+def fwd_ext(u, delta, A, B, C, D_, delta_bias_, delta_softplus, nrows: int = 1, rev_mask: int = 0,
+            u_gshift: int = 0, need_x: bool = True) -> List[torch.Tensor]:
     """``fwd`` plus the two extensions of include/sigma_scan.h used by the fused SS2D path:
-    ``n_rev_groups`` (the last groups scan backwards by addressing) and ``u_row_mod`` (u has only
-    ``u_row_mod`` physical rows; channel row r reads row r % u_row_mod)."""
+    ``rev_mask`` (bit g: group g scans backwards, by addressing) and ``u_gshift`` (group g reads
+    the u rows of group g >> u_gshift; u has dim >> u_gshift rows)."""
     lib = _capi.load()
-    sizes = _check_common(u, delta, A, B, C, D_, delta_bias_, nrows, u_row_mod)
+    sizes = _check_common(u, delta, A, B, C, D_, delta_bias_, nrows, u_gshift)
     batch, dim, seqlen, dstate, _ = sizes
     n_chunks = (seqlen + _capi.SIGMA_SCAN_CHUNK - 1) // _capi.SIGMA_SCAN_CHUNK
     out = torch.empty_like(delta)                                   # selective_scan.cpp:226
@@ -131,7 +132,7 @@ def fwd_ext(u, delta, A, B, C, D_, delta_bias_, delta_softplus, nrows: int = 1, 
         return [out, x]
     fp = _capi.FwdParams()
     _fill_fwd(fp, u, delta, A, B, C, D_, delta_bias_, out, x if need_x else None, delta_softplus, sizes,
-              n_rev_groups, u_row_mod)
+              rev_mask, u_gshift)
     with torch.cuda.device(u.device):                               # CUDAGuard, :240
         stream = torch.cuda.current_stream(u.device).cuda_stream    # :241
         key = (batch, dim, seqlen, dstate, sizes[4], u.element_size())
@@ -147,16 +148,19 @@ def bwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B: torch.Tensor, 
     return bwd_ext(u, delta, A, B, C, D_, delta_bias_, dout, x_, delta_softplus, nrows=nrows)
 
 
-def bwd_ext(u, delta, A, B, C, D_, delta_bias_, dout, x_, delta_softplus, nrows: int = 1, n_rev_groups: int = 0,
-            u_row_mod: int = 0) -> List[Optional[torch.Tensor]]:
+def bwd_ext(u, delta, A, B, C, D_, delta_bias_, dout, x_, delta_softplus, nrows: int = 1, rev_mask: int = 0,
+            u_gshift: int = 0, dout_gshift: int = 0, dB_out: Optional[torch.Tensor] = None,
+            dC_out: Optional[torch.Tensor] = None) -> List[Optional[torch.Tensor]]:
     """``bwd`` with the extensions of ``fwd_ext``.  du has one row per CHANNEL row (batch, dim, L)
-    even when u_row_mod folds several channel rows onto one u row."""
+    even when u_gshift folds several groups onto one copy of u; ``dout_gshift`` does the same for
+    dout.  ``dB_out`` / ``dC_out``: optional fp32 (B, G, N, L) views (stride(-1) == 1) the kernel
+    writes dB / dC into directly (e.g. slices of the gradient of the x_proj output)."""
     lib = _capi.load()
-    sizes = _check_common(u, delta, A, B, C, D_, delta_bias_, nrows, u_row_mod)
+    sizes = _check_common(u, delta, A, B, C, D_, delta_bias_, nrows, u_gshift)
     batch, dim, seqlen, dstate, n_groups = sizes
     _check(dout.dtype == u.dtype, "dout must have the dtype of u")
     _check(dout.is_cuda, "dout must be a GPU tensor")
-    _check(tuple(dout.shape) == (batch, dim, seqlen), "dout must have shape (batch_size, dim, seqlen)")
+    _check(tuple(dout.shape) == (batch, dim >> dout_gshift, seqlen), "dout must have shape (batch_size, dim, seqlen)")
     _check(dout.stride(-1) == 1 or seqlen <= 1, "dout.stride(-1) must be 1")
     n_chunks = (seqlen + _capi.SIGMA_SCAN_CHUNK - 1) // _capi.SIGMA_SCAN_CHUNK
     if n_chunks > 1 or seqlen > _capi.SIGMA_SCAN_CKPT_PITCH:
@@ -169,13 +173,22 @@ def bwd_ext(u, delta, A, B, C, D_, delta_bias_, dout, x_, delta_softplus, nrows:
     ddelta = torch.empty_like(delta)
     dA = torch.zeros_like(A)
     # fully written by the library (deterministic two-stage sum), so no zero fill is needed
-    dB = torch.empty_like(B, dtype=torch.float32) if batch > 0 and seqlen > 0 else torch.zeros_like(B, dtype=torch.float32)
-    dC = torch.empty_like(C, dtype=torch.float32) if batch > 0 and seqlen > 0 else torch.zeros_like(C, dtype=torch.float32)
+    if dB_out is not None:
+        _check(dB_out.dtype == torch.float32 and tuple(dB_out.shape) == tuple(B.shape) and dB_out.stride(-1) == 1 and
+               dC_out is not None and dC_out.dtype == torch.float32 and tuple(dC_out.shape) == tuple(C.shape) and
+               dC_out.stride(-1) == 1, "dB_out / dC_out must be fp32 views shaped like B / C")
+        dB, dC = dB_out, dC_out
+    elif batch > 0 and seqlen > 0:
+        dB = torch.empty(B.shape, dtype=torch.float32, device=B.device)
+        dC = torch.empty(C.shape, dtype=torch.float32, device=C.device)
+    else:
+        dB, dC = torch.zeros_like(B, dtype=torch.float32), torch.zeros_like(C, dtype=torch.float32)
     dD = torch.zeros_like(D_) if D_ is not None else None
     ddelta_bias = torch.zeros_like(delta_bias_) if delta_bias_ is not None else None
     if batch > 0 and seqlen > 0:
         bp = _capi.BwdParams()
-        _fill_fwd(bp.fwd, u, delta, A, B, C, D_, delta_bias_, None, x_, delta_softplus, sizes, n_rev_groups, u_row_mod)
+        _fill_fwd(bp.fwd, u, delta, A, B, C, D_, delta_bias_, None, x_, delta_softplus, sizes, rev_mask, u_gshift)
+        bp.dout_group_shift = int(dout_gshift)
         bp.dout, bp.du, bp.ddelta = _ptr(dout), _ptr(du), _ptr(ddelta)
         bp.dA, bp.dB, bp.dC, bp.dD, bp.ddelta_bias = _ptr(dA), _ptr(dB), _ptr(dC), _ptr(dD), _ptr(ddelta_bias)
         bp.dout_batch_stride, bp.dout_d_stride = dout.stride(0), dout.stride(1)
@@ -195,4 +208,6 @@ def bwd_ext(u, delta, A, B, C, D_, delta_bias_, dout, x_, delta_softplus, nrows:
             key = (batch, dim, seqlen, dstate, n_groups, u.element_size())
             _launch("bwd", key, lambda: _capi.check(
                 lib.sigma_selective_scan_bwd(ctypes.byref(bp), ctypes.c_void_p(stream)), "selective_scan_bwd"))
-    return [du, ddelta, dA, dB.to(B.dtype), dC.to(C.dtype), dD, ddelta_bias]   # :360
+    if dB_out is None:
+        dB, dC = dB.to(B.dtype), dC.to(C.dtype)                                  # :360
+    return [du, ddelta, dA, dB, dC, dD, ddelta_bias]

@@ -1,0 +1,115 @@
+"""Fused core of SS2D (``cross_selective_scan``, reference models/encoders/vmamba.py:165-226)
+as ONE autograd function around the gfx950 scan kernels.
+
+What the reference does per SS2D call (and what autograd then mirrors in backward):
+``CrossScan`` materialises 4 permuted copies of x (vmamba.py:80-98), two einsums project every
+copy (x_proj, dt_proj: :193-199), 5 ``.contiguous()/.float()`` copies feed the CUDA operator
+(:201-207), ``CrossMerge`` un-flips / un-transposes and adds (:100-121).
+
+Here the four directions are never materialised:
+
+* only TWO physical copies of x exist (row-major and column-major order); the operator reads
+  them for four groups through ``u_group_shift`` and runs the two flipped directions backwards by
+  addressing (``rev_group_mask``) -- include/sigma_scan.h;
+* x_proj / dt_proj act point-wise along the sequence, so they are applied to the two memory
+  orders in natural order (they commute with the flip); the scan reads delta / B / C of a flipped
+  direction at L-1-l.  B and C are strided views of the projection output, dB / dC are written by
+  the kernel straight into the gradient of that output -- no split / cat / contiguous copies;
+* directions are processed in the group order [0, 2, 1, 3] (both directions of one memory order
+  adjacent) so that the projection output of a stacked-weight GEMM IS the (B, G, N, L) operand;
+* CrossMerge is two adds and one transposed add; its adjoint hands the SAME gradient to the two
+  directions of a memory order (``dout_group_shift``) instead of four flipped copies.
+
+Parameter layout is the reference's (x_proj_weight (4, R+2N, d), dt_projs_weight (4, d, R),
+dt_projs_bias (4, d), A_logs (4d, N), Ds (4d)); the permutation to kernel group order touches only
+these small tensors.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import selective_scan_cuda_core as _core
+
+# kernel group g -> reference direction k.  g = 2*j + i with j = memory order (0 row-major,
+# 1 column-major) and i = flipped; reference k = j + 2*i (vmamba.py:84-89).  Self-inverse.
+_PERM = (0, 2, 1, 3)
+_REV_MASK = 0b1010
+
+
+def _two_orders(x4: torch.Tensor) -> torch.Tensor:
+    """(B, d, H, W) -> (B, 2, d, L): [row-major, column-major] sequences of the same image."""
+    B, d, H, W = x4.shape
+    out = x4.new_empty(B, 2, d, H * W)
+    out[:, 0].view(B, d, H, W).copy_(x4)
+    out[:, 1].view(B, d, W, H).copy_(x4.transpose(2, 3))
+    return out
+
+
+class SS2DCoreFn(torch.autograd.Function):
+    """y = CrossMerge(selective_scan(CrossScan(x), ...)) for x (B, d, H, W) -> y (B, d, H*W)."""
+
+    @staticmethod
+    def forward(ctx, x, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds):
+        B, d, H, W = x.shape
+        L = H * W
+        K, c, _ = x_proj_weight.shape
+        R = dt_projs_weight.shape[2]
+        N = A_logs.shape[1]
+        if K != 4:
+            raise RuntimeError("SS2DCoreFn expects the 4-direction parameter stack")
+        x = x.float()
+        perm = list(_PERM)
+        xs2 = _two_orders(x)                                                   # (B, 2, d, L)
+        Wst = x_proj_weight.float()[perm].reshape(2, 2 * c, d)                 # [order j][(flip i, row)][d]
+        p4 = torch.matmul(Wst.unsqueeze(0), xs2).view(B, 4, c, L)              # == (B, group g, R+2N, L)
+        dtw = dt_projs_weight.float()[perm]                                    # (4, d, R)
+        delta = torch.matmul(dtw.unsqueeze(0), p4[:, :, :R])                   # (B, 4, d, L)
+        A = (-torch.exp(A_logs.float())).view(4, d, N)[perm].reshape(4 * d, N)
+        Dp = Ds.float().view(4, d)[perm].reshape(-1)
+        bias = dt_projs_bias.float()[perm].reshape(-1)
+        Bv, Cv = p4[:, :, R:R + N], p4[:, :, R + N:]
+        need_x = any(ctx.needs_input_grad)
+        out, ck = _core.fwd_ext(xs2.view(B, 2 * d, L), delta.view(B, 4 * d, L), A, Bv, Cv, Dp, bias, True,
+                                rev_mask=_REV_MASK, u_gshift=1, need_x=need_x)
+        ys = out.view(B, 4, d, L)
+        y = ys[:, 0] + ys[:, 1]
+        y_cm = ys[:, 2] + ys[:, 3]
+        y += y_cm.view(B, d, W, H).transpose(2, 3).reshape(B, d, L)
+        ctx.save_for_backward(xs2, p4, delta, A, Dp, bias, ck, Wst, dtw)
+        ctx.dims = (B, d, H, W, c, R, N)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xs2, p4, delta, A, Dp, bias, ck, Wst, dtw = ctx.saved_tensors
+        B, d, H, W, c, R, N = ctx.dims
+        L = H * W
+        perm = list(_PERM)
+        g2 = _two_orders(dy.float().reshape(B, d, H, W))                       # CrossMerge^T: 2 planes, not 4
+        dp4 = torch.empty_like(p4)
+        Bv, Cv = p4[:, :, R:R + N], p4[:, :, R + N:]
+        du, ddelta, dA, _, _, dD, dbias = _core.bwd_ext(
+            xs2.view(B, 2 * d, L), delta.view(B, 4 * d, L), A, Bv, Cv, Dp, bias, g2.view(B, 2 * d, L), ck, True,
+            rev_mask=_REV_MASK, u_gshift=1, dout_gshift=1, dB_out=dp4[:, :, R:R + N], dC_out=dp4[:, :, R + N:])
+        ddelta4 = ddelta.view(B, 4, d, L)
+        # dt_proj: delta = dtw @ p4[:R]
+        dp4[:, :, :R] = torch.matmul(dtw.transpose(1, 2).unsqueeze(0), ddelta4)
+        d_dtw = torch.matmul(ddelta4, p4[:, :, :R].transpose(-1, -2)).sum(0)   # (4, d, R)
+        # x_proj: p = Wst @ xs2
+        dp2 = dp4.view(B, 2, 2 * c, L)
+        dxs2 = torch.matmul(Wst.transpose(1, 2).unsqueeze(0), dp2)             # (B, 2, d, L)
+        du4 = du.view(B, 2, 2, d, L)
+        dxs2 += du4[:, :, 0]
+        dxs2 += du4[:, :, 1]
+        dWst = torch.matmul(dp2, xs2.transpose(-1, -2)).sum(0)                 # (2, 2c, d)
+        dx = dxs2[:, 0].reshape(B, d, H, W) + dxs2[:, 1].view(B, d, W, H).transpose(2, 3)
+        d_xproj = dWst.view(4, c, d)[perm]
+        d_dtw = d_dtw[perm]
+        dA_logs = (dA * A).view(4, d, N)[perm].reshape(4 * d, N)               # A = -exp(A_logs)
+        dDs = dD.view(4, d)[perm].reshape(-1)
+        dbias = dbias.view(4, d)[perm]
+        return dx, d_xproj, d_dtw, dbias, dA_logs, dDs
+
+
+def ss2d_core(x, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds):
+    return SS2DCoreFn.apply(x, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds)

@@ -107,7 +107,7 @@ def test_options_and_launch_plan():
     assert lib.sigma_scan_bwd_workspace_bytes(ctypes.byref(bp)) == (0 if P == 1 else 2 * P * 2 * 2 * 8 * 372 * 4)
     # extension fields are validated
     bad = _params(batch=1, dim=8, seqlen=64, dstate=4, n_groups=2, n_chunks=1)
-    bad.n_rev_groups = 3
+    bad.rev_group_mask = 0b100
     assert lib.sigma_scan_fwd_plan(ctypes.byref(bad), ctypes.byref(plan)) != 0
 
 

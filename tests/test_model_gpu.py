@@ -54,9 +54,46 @@ def test_train_mode_step_and_determinism_of_forward():
     with torch.no_grad():
         a = model(rgb.cuda(), x.cuda())
         b = model(rgb.cuda(), x.cuda())
-    assert torch.equal(a, b)
+        fa = model.backbone(rgb.cuda(), x.cuda())
+        fb = model.backbone(rgb.cuda(), x.cuda())
+    # the encoder + fusion path (HIP scans, GEMMs, depthwise convs) is bit-reproducible; MIOpen's dense
+    # 3x3 convolutions in the decoder pick an atomics-based algorithm, so logits repeat only to rounding
+    assert all(torch.equal(p, q) for p, q in zip(fa, fb))
+    torch.testing.assert_close(a, b, rtol=0, atol=1e-4)
     model.train()                                     # DropPath active: still finite, all params get grads
     loss = model(rgb.cuda(), x.cuda(), label.cuda())
     loss.backward()
     assert torch.isfinite(loss)
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+
+
+@pytest.mark.parametrize("shape", [(2, 24, 15, 20, 16), (1, 48, 7, 9, 4), (2, 16, 30, 40, 16), (1, 32, 12, 107, 4)])
+def test_fused_ss2d_core_equals_plain_autograd_formulation(shape):
+    """sigma_amd.ss2d_fused (two copies of x, reversed groups by addressing, dB/dC written in place)
+    against CrossScan / einsum / selective_scan_fn / CrossMerge written with plain torch ops
+    (vmamba.py:165-226), values and all six gradients."""
+    import importlib
+    import torch.nn as nn
+    vm = importlib.import_module("sigma_amd.models.encoders.vmamba")
+    B, d, H, W, N = shape
+    torch.manual_seed(0)
+    blk = vm.SS2D(d_model=d // 2, d_state=N).cuda()
+    x = torch.randn(B, d, H, W, device="cuda")
+    dy = torch.randn(B, H, W, d, device="cuda")
+    params = [blk.x_proj_weight, blk.dt_projs_weight, blk.dt_projs_bias, blk.A_logs, blk.Ds]
+    res = {}
+    for fused in (True, False):
+        vm._FUSED_SS2D = fused
+        try:
+            xi = x.clone().requires_grad_()
+            for p in params:
+                p.grad = None
+            y = vm.ss2d_scan(xi, *params, nn.Identity())
+            y.backward(dy)
+            res[fused] = [y.detach()] + [xi.grad] + [p.grad.clone() for p in params]
+        finally:
+            vm._FUSED_SS2D = True
+    names = ["y", "dx", "dx_proj", "ddt_w", "ddt_b", "dA_logs", "dDs"]
+    for n, a, b in zip(names, res[True], res[False]):
+        scale = float(b.abs().max()) + 1e-6
+        assert float((a - b).abs().max()) <= 2e-4 * scale + 1e-5, (n, float((a - b).abs().max()), scale)

@@ -216,30 +216,33 @@ def test_checkpoint_tensor_shape_and_documented_layout():
         torch.testing.assert_close(x[:, :, j // 2, :, j % 2], st, rtol=1e-3, atol=1e-4)
 
 
-def _run_hip_ext(u, delta, A, B, C, D, bias, dout, n_rev_groups=0, u_row_mod=0):
+def _run_hip_ext(u, delta, A, B, C, D, bias, dout, rev_mask=0, u_gshift=0, dout_gshift=0):
     """fwd + bwd through the extended operator entry (reverse groups / shared u rows)."""
     core = _core()
     dev = "cuda"
     args = [t.to(dev) for t in (u, delta, A, B, C, D, bias)]
-    out, x = core.fwd_ext(*args, True, n_rev_groups=n_rev_groups, u_row_mod=u_row_mod)
-    grads = core.bwd_ext(*args, dout.to(dev), x, True, n_rev_groups=n_rev_groups, u_row_mod=u_row_mod)
+    out, x = core.fwd_ext(*args, True, rev_mask=rev_mask, u_gshift=u_gshift)
+    grads = core.bwd_ext(*args, dout.to(dev), x, True, rev_mask=rev_mask, u_gshift=u_gshift, dout_gshift=dout_gshift)
     return out.cpu(), [g.cpu() for g in grads]
 
 
 @pytest.mark.parametrize("L", [300, 640, 1200, 1283, 2564, 4800])
-def test_reversed_groups_equal_flipped_inputs(L):
-    """CrossScan's flip done by addressing: with the last two of four groups reversed, the result
+@pytest.mark.parametrize("mask", [0b1100, 0b1010])
+def test_reversed_groups_equal_flipped_inputs(L, mask):
+    """CrossScan's flip done by addressing: with some of the four groups reversed, the result
     must equal the plain operator applied to explicitly flipped copies (vmamba.py:80-121)."""
     batch, KD, N, G = 2, 32, 16, 4
     u, delta, A, B, C, D, bias, dout = _model_like(batch, KD, L, N, G, seed=11)
-    out, grads = _run_hip_ext(u, delta, A, B, C, D, bias, dout, n_rev_groups=2)
-    half = KD // 2
+    out, grads = _run_hip_ext(u, delta, A, B, C, D, bias, dout, rev_mask=mask)
+    rpg = KD // G
+    revs = [(mask >> g) & 1 for g in range(G)]
 
-    def flip_rows(t):            # (B, KD, L): rows of groups 2, 3 flipped along L
-        return torch.cat([t[:, :half], t[:, half:].flip(-1)], dim=1)
+    def flip_rows(t):            # (B, KD, L): rows of reversed groups flipped along L
+        return torch.cat([t[:, g * rpg:(g + 1) * rpg].flip(-1) if revs[g] else t[:, g * rpg:(g + 1) * rpg]
+                          for g in range(G)], dim=1)
 
     def flip_groups(t):          # (B, G, N, L)
-        return torch.cat([t[:, :2], t[:, 2:].flip(-1)], dim=1)
+        return torch.stack([t[:, g].flip(-1) if revs[g] else t[:, g] for g in range(G)], dim=1)
 
     so = _oracle()
     uf, df, Bf, Cf, gf = flip_rows(u), flip_rows(delta), flip_groups(B), flip_groups(C), flip_rows(dout)
@@ -253,19 +256,30 @@ def test_reversed_groups_equal_flipped_inputs(L):
                                    msg=lambda m, name=name: f"d{name}: {m}")
 
 
-def test_shared_u_rows():
-    """u_row_mod: channel row r reads u row r % mod (two physical copies serve four directions)."""
+def test_shared_u_and_dout_rows():
+    """u_gshift / dout_gshift: groups 2j and 2j+1 share one physical copy of u (and of dout), as the
+    forward and the flipped direction of one memory order do in SS2D; dB / dC go straight into views."""
     batch, KD, L, N, G = 1, 32, 900, 4, 4
     u, delta, A, B, C, D, bias, dout = _model_like(batch, KD, L, N, G, seed=13)
-    u_half = u[:, :KD // 2].contiguous()
-    u_full = torch.cat([u_half, u_half], dim=1)
-    out, grads = _run_hip_ext(u_half, delta, A, B, C, D, bias, dout, u_row_mod=KD // 2)
+    rpg = KD // G
+    u_half = torch.cat([u[:, 0:rpg], u[:, 2 * rpg:3 * rpg]], dim=1).contiguous()          # groups 0 and 2
+    g_half = torch.cat([dout[:, 0:rpg], dout[:, 2 * rpg:3 * rpg]], dim=1).contiguous()
+    u_full = torch.cat([u_half[:, :rpg]] * 2 + [u_half[:, rpg:]] * 2, dim=1)
+    g_full = torch.cat([g_half[:, :rpg]] * 2 + [g_half[:, rpg:]] * 2, dim=1)
+    core = _core()
+    dev = "cuda"
+    args = [t.to(dev) for t in (u_half, delta, A, B, C, D, bias)]
+    out, x = core.fwd_ext(*args, True, u_gshift=1)
+    big = torch.zeros(batch, G, 2 * N + 3, L, device=dev)
+    grads = core.bwd_ext(*args, g_half.to(dev), x, True, u_gshift=1, dout_gshift=1,
+                         dB_out=big[:, :, 3:3 + N], dC_out=big[:, :, 3 + N:])
+    assert grads[3].data_ptr() == big[:, :, 3:3 + N].data_ptr() and float(big[:, :, :3].abs().max()) == 0.0
     so = _oracle()
     ref = so.selective_scan_oracle(u_full, delta, A, B, C, D, bias, True, acc64=True)
-    torch.testing.assert_close(out, ref, rtol=6e-4, atol=2e-3)
-    rg = so.selective_scan_oracle_bwd(u_full, delta, A, B, C, D, bias, dout, True)
+    torch.testing.assert_close(out.cpu(), ref, rtol=6e-4, atol=2e-3)
+    rg = so.selective_scan_oracle_bwd(u_full, delta, A, B, C, D, bias, g_full, True)
     for name, g, r in zip(["u", "delta", "A", "B", "C", "D", "bias"], grads, rg):   # du stays per channel row
-        torch.testing.assert_close(g, r, rtol=3e-3, atol=2e-3 + 2e-4 * float(r.abs().max()),
+        torch.testing.assert_close(g.cpu(), r, rtol=3e-3, atol=2e-3 + 2e-4 * float(r.abs().max()),
                                    msg=lambda m, name=name: f"d{name}: {m}")
 
 
