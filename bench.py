@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--classes", type=int, default=40)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--conv-autotune", action="store_true", help="torch.backends.cudnn.benchmark = True (slow start)")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU oracle work")
     ap.add_argument("--kernel-report", default="", help="write the per-kernel-shape table (json) here")
     return ap.parse_args()
@@ -162,6 +163,10 @@ def main():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    # train.py:57 sets cudnn.benchmark = True; on ROCm that is MIOpen's exhaustive find mode, which
+    # for this model's ~60 convolution configurations runs for more than 15 minutes before the
+    # first step returns (measured), so the default here is MIOpen's immediate mode.
+    torch.backends.cudnn.benchmark = bool(a.conv_autotune)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world)   # "nccl" is RCCL on ROCm

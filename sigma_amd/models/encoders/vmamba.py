@@ -253,7 +253,11 @@ class ChannelAttention(nn.Module):
         self.sigmoid = nn.Sigmoid()
 
     def forward(self, x):
-        gate = self.fc(self.avg_pool(x)) + self.fc(self.max_pool(x))
+        # global pools as plain reductions (AdaptiveMaxPool2d(1) runs a 0.9 ms one-thread-per-output
+        # kernel on ROCm and keeps an index tensor for backward); same values and gradients
+        pooled = torch.cat([x.mean(dim=(2, 3), keepdim=True), x.amax(dim=(2, 3), keepdim=True)], dim=0)
+        g = self.fc(pooled)
+        gate = g[:x.shape[0]] + g[x.shape[0]:]
         return x * self.sigmoid(gate)
 
 
