@@ -58,24 +58,6 @@ def parse():
     return ap.parse_args()
 
 
-def group_weight(module: nn.Module, lr: float):
-    """Optimizer groups of the reference (utils/init_func.py:33-58): Linear/conv weights decay,
-    norms and biases do not; raw nn.Parameters owned directly by the Mamba blocks end up in no
-    group and are therefore never stepped -- reproduced on purpose."""
-    decay, no_decay = [], []
-    for m in module.modules():
-        if isinstance(m, (nn.Linear, nn.Conv1d, nn.Conv2d, nn.Conv3d, nn.ConvTranspose2d)):
-            decay.append(m.weight)
-            if m.bias is not None:
-                no_decay.append(m.bias)
-        elif isinstance(m, (nn.LayerNorm, nn.GroupNorm, nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d)):
-            if m.weight is not None:
-                no_decay.append(m.weight)
-            if m.bias is not None:
-                no_decay.append(m.bias)
-    return [dict(params=decay, lr=lr), dict(params=no_decay, weight_decay=0.0, lr=lr)]
-
-
 class KernelTimer:
     """HIP-event timing of every scan launch inside the timed region, on the launch stream."""
 
@@ -172,6 +154,7 @@ def main():
         dist.init_process_group(backend="nccl", rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
 
     from sigma_amd import selective_scan_cuda_core as core
+    from sigma_amd import train_step as ts
     from sigma_amd.models.builder import EncoderDecoder
 
     timer = KernelTimer()
@@ -192,44 +175,19 @@ def main():
     finally:
         os.chdir(cwd)
     model.to(dev).train()
-    opt = torch.optim.AdamW(group_weight(model, 6e-5), lr=6e-5, betas=(0.9, 0.999), weight_decay=0.01)
-    net = model
-    if world > 1:
-        net = nn.parallel.DistributedDataParallel(model, device_ids=[local], output_device=local,
-                                                  find_unused_parameters=False)   # train.py:107
+    opt = ts.make_optimizer(model)
+    net = ts.wrap_ddp(model, dev, world)                     # train.py:107
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     rgb = torch.randn(a.batch, 3, a.height, a.width, generator=g).to(dev)
     mx = torch.randn(a.batch, 3, a.height, a.width, generator=g).to(dev)
     label = torch.randint(0, a.classes, (a.batch, a.height, a.width), generator=g).to(dev)
+    step = ts.make_step(net, opt, (rgb, mx, label), world)
 
-    def step():
-        opt.zero_grad(set_to_none=True)
-        loss = net(rgb, mx, label)
-        if world > 1:                                        # train.py:168 (logging all-reduce)
-            red = loss.detach().clone()
-            dist.all_reduce(red, op=dist.ReduceOp.SUM)
-        loss.backward()
-        opt.step()
-        return loss
+    def start_timers():
+        timer.enabled = True
 
-    for _ in range(a.warmup):
-        step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    timer.enabled = True
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        loss = step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    elapsed, loss = ts.timed_steps(step, a.steps, a.warmup, dev, world, on_timed_start=start_timers)
     timer.enabled = False
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
 
     if rank == 0:
         table = timer.table()
@@ -248,6 +206,13 @@ def main():
                         avg_launch_us=round(d["avg_us"], 1), launches=d["launches"],
                         share_of_scan_time=round(d["total_ms"] / scan_ms, 3),
                         scan_share_of_step=round(scan_ms / (elapsed * 1e3), 3))
+        roof_fwd = None
+        fwd_rows = [r for r in rows if r["kernel"] == "scan_fwd"]
+        if fwd_rows:
+            d = fwd_rows[0]
+            roof_fwd = dict(bound="hbm", achieved=round(d["GBs"], 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                            frac=round(d["GBs"] / HBM_PEAK_GBS, 4), kernel=d["kernel"], shape=d["shape"],
+                            avg_launch_us=round(d["avg_us"], 1), launches=d["launches"])
         if a.kernel_report:
             os.makedirs(os.path.dirname(os.path.abspath(a.kernel_report)) or ".", exist_ok=True)
             with open(a.kernel_report, "w") as f:
@@ -255,8 +220,7 @@ def main():
         cpu = None
         if world == 1 and not a.no_cpu_baseline:
             cpu = cpu_baseline(a.backbone, a.height, a.width, a.cpu_budget)
-        images = a.batch * world * a.steps
-        line = dict(metric=f"images/sec fwd+bwd {a.backbone} {a.height}x{a.width}", value=round(images / elapsed, 3),
+        line = dict(metric=f"images/sec fwd+bwd {a.backbone} {a.height}x{a.width}", value=round(ts.throughput(a.batch, world, a.steps, elapsed), 3),
                     unit="images/s", n_gpus=world, steps=a.steps, warmup=a.warmup,
                     ms_per_step=round(elapsed / a.steps * 1e3, 2), higher_is_better=True, scaling="weak",
                     vs_baseline=None, dtype="f32", data="synthetic",
@@ -264,7 +228,7 @@ def main():
                                          f"{a.classes} classes, fp32", per_gpu_batch=a.batch,
                                 global_batch=a.batch * world, parallelism=f"dp{world}",
                                 loss=round(float(loss.item()), 4)),
-                    roofline=roof, cpu_baseline=cpu)
+                    roofline=roof, roofline_fwd=roof_fwd, cpu_baseline=cpu)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -1,0 +1,99 @@
+"""The reference's training step and its multi-GPU plumbing, restated for reuse by bench.py and
+the CPU (gloo) tests.
+
+Reference: train.py:59-63 (seed = local rank), :82-107 (model, optimizer, DistributedDataParallel
+with find_unused_parameters=False), :160-172 (loss = model(imgs, modal_xs, gts); all-reduce of the
+loss for logging; zero_grad; backward; step) and utils/init_func.py:33-58 (optimizer groups).
+
+The forward of an image pair is independent of every other pair (LayerNorm only, no SyncBN), so
+the path shards per image: one process per GPU, a full replica each, ONE collective on the data
+path -- DDP's bucketed gradient all-reduce (RCCL over xGMI when backend == "nccl") -- plus the
+4-byte loss all-reduce the reference does for logging.
+"""
+from __future__ import annotations
+
+import time
+from typing import Callable, Tuple
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+
+def group_weight(module: nn.Module, lr: float):
+    """Optimizer groups of the reference (utils/init_func.py:33-58): Linear/conv weights decay,
+    norms and biases do not; raw nn.Parameters owned directly by the Mamba blocks end up in no
+    group and are therefore never stepped -- reproduced on purpose."""
+    decay, no_decay = [], []
+    for m in module.modules():
+        if isinstance(m, (nn.Linear, nn.Conv1d, nn.Conv2d, nn.Conv3d, nn.ConvTranspose2d)):
+            decay.append(m.weight)
+            if m.bias is not None:
+                no_decay.append(m.bias)
+        elif isinstance(m, (nn.LayerNorm, nn.GroupNorm, nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d)):
+            if m.weight is not None:
+                no_decay.append(m.weight)
+            if m.bias is not None:
+                no_decay.append(m.bias)
+    return [dict(params=decay, lr=lr), dict(params=no_decay, weight_decay=0.0, lr=lr)]
+
+
+def make_optimizer(model: nn.Module, lr: float = 6e-5, weight_decay: float = 0.01):
+    """AdamW as configured by the reference (train.py:95-100, configs/config_nyu.py:97-100)."""
+    return torch.optim.AdamW(group_weight(model, lr), lr=lr, betas=(0.9, 0.999), weight_decay=weight_decay)
+
+
+def wrap_ddp(model: nn.Module, device: torch.device, world: int) -> nn.Module:
+    """train.py:107.  find_unused_parameters=False: every parameter must receive a gradient."""
+    if world <= 1:
+        return model
+    ids = [device.index] if device.type == "cuda" else None
+    return nn.parallel.DistributedDataParallel(model, device_ids=ids, output_device=ids[0] if ids else None,
+                                               find_unused_parameters=False)
+
+
+def make_step(net: nn.Module, opt, batch: Tuple[torch.Tensor, ...], world: int) -> Callable[[], torch.Tensor]:
+    """One training step of train.py:160-172 on a fixed (synthetic) batch."""
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = net(*batch)
+        if world > 1:                                        # train.py:168 (logging all-reduce)
+            red = loss.detach().clone()
+            dist.all_reduce(red, op=dist.ReduceOp.SUM)
+        loss.backward()
+        opt.step()
+        return loss
+    return step
+
+
+def _sync(device: torch.device, world: int) -> None:
+    if world > 1:
+        dist.barrier()
+    if device.type == "cuda":
+        torch.cuda.synchronize(device)
+
+
+def timed_steps(step: Callable[[], torch.Tensor], steps: int, warmup: int, device: torch.device, world: int,
+                on_timed_start: Callable[[], None] = lambda: None):
+    """`warmup` untimed steps, then exactly `steps` steps between barrier + synchronize pairs.
+    Returns (seconds of the slowest rank, last loss)."""
+    loss = None
+    for _ in range(warmup):
+        loss = step()
+    _sync(device, world)
+    on_timed_start()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    _sync(device, world)
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed, loss
+
+
+def throughput(per_rank_batch: int, world: int, steps: int, elapsed: float) -> float:
+    """Whole-job images/s under weak scaling: every rank processes per_rank_batch pairs per step."""
+    return per_rank_batch * world * steps / elapsed

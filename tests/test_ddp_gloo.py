@@ -1,0 +1,109 @@
+"""N > 1 path on CPU: two processes, gloo, the same step / timing / grouping code bench.py runs
+with RCCL (sigma_amd/train_step.py).  The model here is a small CPU stand-in with the structural
+features that matter for the data-parallel path (LayerNorm only, raw nn.Parameters that the
+reference's optimizer grouping skips, a loss returned by forward); the HIP model itself cannot run
+without a GPU by design."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+from sigma_amd import train_step as ts
+
+
+class TinySeg(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.stem = nn.Conv2d(3, 8, 4, 4)
+        self.norm = nn.LayerNorm(8)
+        self.scale = nn.Parameter(torch.ones(8))          # raw Parameter: in no optimizer group (App. C-4)
+        self.head = nn.Linear(16, 5)
+        self.criterion = nn.CrossEntropyLoss(ignore_index=255)
+
+    def forward(self, rgb, x, label=None):
+        f = torch.cat([self.norm(self.stem(rgb).permute(0, 2, 3, 1)) * self.scale,
+                       self.norm(self.stem(x).permute(0, 2, 3, 1))], dim=-1)
+        logits = self.head(f).permute(0, 3, 1, 2)
+        logits = nn.functional.interpolate(logits, scale_factor=4, mode="bilinear", align_corners=False)
+        return logits if label is None else self.criterion(logits, label)
+
+
+def _batch(rank, n=2):
+    g = torch.Generator().manual_seed(100 + rank)
+    return (torch.randn(n, 3, 16, 16, generator=g), torch.randn(n, 3, 16, 16, generator=g),
+            torch.randint(0, 5, (n, 16, 16), generator=g))
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)                               # identical replicas, as DDP would broadcast
+        model = TinySeg()
+        dev = torch.device("cpu")
+        net = ts.wrap_ddp(model, dev, world)
+        opt = ts.make_optimizer(model, lr=1e-2)
+        step = ts.make_step(net, opt, _batch(rank), world)
+        before = {n: p.detach().clone() for n, p in model.named_parameters()}
+        elapsed, loss = ts.timed_steps(step, steps=2, warmup=1, device=dev, world=world)
+        grads = {n: p.grad.detach().clone() for n, p in model.named_parameters()}
+        moved = {n: bool((p.detach() != before[n]).any()) for n, p in model.named_parameters()}
+        # every rank must report the same (max) time
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        ts_all = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(ts_all, t)
+        if rank == 0:
+            torch.save(dict(grads=grads, moved=moved, times=[float(v) for v in ts_all], loss=float(loss),
+                            params={n: p.detach().clone() for n, p in model.named_parameters()}), out)
+        else:
+            torch.save(dict(grads=grads, params={n: p.detach().clone() for n, p in model.named_parameters()}),
+                       out + ".r1")
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.timeout(180)
+def test_two_rank_gloo_step_matches_single_process_average(tmp_path):
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r0, r1 = torch.load(out), torch.load(out + ".r1")
+    # replicas stay identical: same gradients (all-reduced mean) and same parameters on both ranks
+    for n in r0["grads"]:
+        torch.testing.assert_close(r0["grads"][n], r1["grads"][n], rtol=0, atol=0)
+        torch.testing.assert_close(r0["params"][n], r1["params"][n], rtol=0, atol=0)
+    assert len(set(r0["times"])) == 1 and r0["times"][0] > 0          # max over ranks, agreed by all
+    # reference quirk reproduced: the raw Parameter gets a gradient (and is all-reduced) but is never stepped
+    assert r0["moved"]["stem.weight"] and r0["moved"]["head.bias"] and not r0["moved"]["scale"]
+    # single-process reference of the LAST step's gradient: mean of the two ranks' batch gradients
+    torch.manual_seed(0)
+    ref = TinySeg()
+    ref.load_state_dict({k: v for k, v in r0["params"].items()})       # params AFTER the last step ...
+    # ... so rebuild the params BEFORE it by replaying three steps single-process on the averaged loss
+    torch.manual_seed(0)
+    ref = TinySeg()
+    opt = ts.make_optimizer(ref, lr=1e-2)
+    b0, b1 = _batch(0), _batch(1)
+    for _ in range(3):
+        opt.zero_grad(set_to_none=True)
+        loss = 0.5 * (ref(*b0) + ref(*b1))
+        loss.backward()
+        last = {n: p.grad.detach().clone() for n, p in ref.named_parameters()}
+        opt.step()
+    for n in last:
+        torch.testing.assert_close(r0["grads"][n], last[n], rtol=1e-4, atol=1e-6)
+        torch.testing.assert_close(r0["params"][n], dict(ref.named_parameters())[n].detach(), rtol=1e-4, atol=1e-6)
+
+
+def test_weak_scaling_accounting():
+    assert ts.throughput(8, 1, 5, 2.0) == 20.0
+    assert ts.throughput(8, 8, 5, 2.0) == 160.0
