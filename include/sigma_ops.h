@@ -1,0 +1,55 @@
+/*
+ * sigma_ops.h -- C ABI of the fused layout / stencil operators around the scan in libsigma_hip.so.
+ *
+ * These replace torch op sequences of the reference's SS2D block (models/encoders/vmamba.py), they
+ * have no counterpart in the reference's native code (which only has the selective-scan kernels):
+ *
+ *   sigma_dwconv3x3_silu_fwd / _bwd
+ *       SS2D.forward, vmamba.py:1075-1077:  x = x.permute(0,3,1,2).contiguous(); x = act(conv2d(x))
+ *       with conv2d = nn.Conv2d(d, d, 3, padding=1, groups=d, bias) (vmamba.py:679-683), fused with
+ *       the layout half of CrossScan (vmamba.py:80-89): the activation is written once in row-major
+ *       and once in column-major sequence order, which is all the scan kernels need (the two
+ *       flipped directions are read backwards, see sigma_scan.h rev_group_mask).
+ *
+ * Same conventions as sigma_scan.h: device pointers, float32, contiguous tensors, the callee
+ * enqueues on `stream` (hipStream_t as void*) of the current device, never allocates, never
+ * synchronises; returns 0 or a SIGMA_OPS_ERR_* code.
+ */
+#ifndef SIGMA_OPS_H_
+#define SIGMA_OPS_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum sigma_ops_status {
+    SIGMA_OPS_OK = 0,
+    SIGMA_OPS_ERR_ARG = 1,
+    SIGMA_OPS_ERR_LAUNCH = 5
+};
+
+typedef struct sigma_dwconv_params {
+    int32_t batch, channels, height, width;
+    const float *x;        /* (B, d, H, W)   input of the convolution                              */
+    const float *weight;   /* (d, 1, 3, 3)                                                         */
+    const float *bias;     /* (d) or NULL                                                          */
+    /* forward */
+    float *out2;           /* (B, 2, d, H*W): [:,0] = silu(conv(x)) row-major, [:,1] = the same
+                              image in column-major order (index w*H + h)                          */
+    /* backward */
+    const float *g2;       /* (B, 2, d, H*W) gradient of out2                                      */
+    float *gpre;           /* (B, d, H, W) scratch: gradient w.r.t. the pre-activation            */
+    float *dweight;        /* (d, 1, 3, 3) ACCUMULATED into (caller zeroes)                        */
+    float *dbias;          /* (d) ACCUMULATED into, or NULL                                        */
+    float *dx;             /* (B, d, H, W) fully written                                           */
+} sigma_dwconv_params;
+
+int sigma_dwconv3x3_silu_fwd(const sigma_dwconv_params *params, void *stream);
+int sigma_dwconv3x3_silu_bwd(const sigma_dwconv_params *params, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SIGMA_OPS_H_ */

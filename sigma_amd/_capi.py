@@ -62,6 +62,20 @@ class BwdParams(ctypes.Structure):
     ]
 
 
+class DwConvParams(ctypes.Structure):
+    """mirror of sigma_dwconv_params (include/sigma_ops.h)"""
+    _fields_ = [
+        ("batch", ctypes.c_int32), ("channels", ctypes.c_int32), ("height", ctypes.c_int32), ("width", ctypes.c_int32),
+        ("x", ctypes.c_void_p), ("weight", ctypes.c_void_p), ("bias", ctypes.c_void_p),
+        ("out2", ctypes.c_void_p),
+        ("g2", ctypes.c_void_p), ("gpre", ctypes.c_void_p), ("dweight", ctypes.c_void_p), ("dbias", ctypes.c_void_p),
+        ("dx", ctypes.c_void_p),
+    ]
+
+
+# every symbol include/sigma_ops.h declares
+OPS_SYMBOLS = ("sigma_dwconv3x3_silu_fwd", "sigma_dwconv3x3_silu_bwd")
+
 # every symbol include/sigma_scan.h declares; tests check the library exports all of them
 EXPORTED_SYMBOLS = (
     "sigma_selective_scan_fwd",
@@ -113,6 +127,10 @@ def load() -> ctypes.CDLL:
     lib.sigma_scan_bwd_plan.restype = ctypes.c_int
     lib.sigma_scan_selftest.argtypes = [ctypes.c_void_p]
     lib.sigma_scan_selftest.restype = ctypes.c_int
+    for name in OPS_SYMBOLS:
+        fn = getattr(lib, name)
+        fn.argtypes = [P(DwConvParams), ctypes.c_void_p]
+        fn.restype = ctypes.c_int
     if lib.sigma_scan_abi_version() != SIGMA_SCAN_ABI_VERSION:
         raise SigmaHipUnavailable(
             f"ABI mismatch: library {lib.sigma_scan_abi_version()} vs binding {SIGMA_SCAN_ABI_VERSION}; rebuild")

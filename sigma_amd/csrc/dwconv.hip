@@ -1,0 +1,249 @@
+// dwconv.hip -- depthwise 3x3 convolution + SiLU of SS2D, fused with the CrossScan layout step.
+//
+// Reference (models/encoders/vmamba.py:1075-1077, 679-683):
+//     x = x.permute(0, 3, 1, 2).contiguous();  x = self.act(self.conv2d(x))       # Conv2d(d, d, 3, pad 1, groups=d) + SiLU
+// followed by CrossScan's four permuted copies (vmamba.py:80-98).  On MI355X all of it is HBM-bound
+// stencil / transpose work, so it is one pass: read the (B, d, H, W) plane once, write the activation in
+// BOTH memory orders the scan kernels consume (row-major, and column-major through a padded LDS tile so
+// that both stores are coalesced).  MIOpen serves this shape with its "naive_conv" fallbacks.
+//
+//   fwd :  y = silu(conv3x3(x) + bias)                 -> out[b, 0, c, h*W + w],  out[b, 1, c, w*H + h]
+//   bwd1:  gpre = (g[b,0,c,h*W+w] + g[b,1,c,w*H+h]) * silu'(conv3x3(x) + bias)    (pre-activation recomputed)
+//          dW[c, :, :] += sum gpre * x(shifted),  dbias[c] += sum gpre             (block reduce + one atomic each)
+//   bwd2:  dx = correlate(gpre, W)                                                  (transposed stencil)
+//
+// One workgroup = one 32x32 spatial tile of one (batch, channel) plane, 256 threads as 32 x 8, four rows
+// per thread.  Neighbour taps come straight from global memory (each value is re-used 9x out of L1).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/sigma_ops.h"
+
+namespace sigma {
+
+namespace {
+
+constexpr int kTile = 32;
+
+struct DwArgs {
+    const float* x; const float* w; const float* bias;
+    float* out2;            // fwd: (B, 2, d, L)
+    const float* g2;        // bwd1: (B, 2, d, L)
+    float* gpre;            // bwd1 out / bwd2 in: (B, d, H, W)
+    float* dw; float* dbias;   // (d, 9), (d): accumulated
+    float* dx;              // bwd2 out: (B, d, H, W)
+    int B, d, H, W;
+};
+
+__device__ __forceinline__ float sigmoidf_fast(float v) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-v * 1.4426950408889634f));
+}
+
+__device__ __forceinline__ float wave_sum_shfl(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// taps t[0..8] = x[h-1..h+1][w-1..w+1] (0 outside the plane)
+__device__ __forceinline__ void load_taps(const float* __restrict__ plane, int h, int w, int H, int W, float (&t)[9]) {
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+        const int hh = h + dy - 1;
+        const bool hin = hh >= 0 && hh < H;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int ww = w + dx - 1;
+            t[dy * 3 + dx] = (hin && ww >= 0 && ww < W) ? plane[(long)hh * W + ww] : 0.0f;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) dwconv_silu_fwd_kernel(const DwArgs a) {
+    __shared__ float tile[kTile][kTile + 1];
+    const int H = a.H, W = a.W;
+    const long L = (long)H * W;
+    const int tw = (W + kTile - 1) / kTile, th = (H + kTile - 1) / kTile;
+    const int plane_id = blockIdx.x / (tw * th);           // b * d + c
+    const int tile_id = blockIdx.x - plane_id * (tw * th);
+    const int c = plane_id % a.d;
+    const int b = plane_id / a.d;
+    const int w0 = (tile_id % tw) * kTile, h0 = (tile_id / tw) * kTile;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float* __restrict__ plane = a.x + (long)plane_id * L;
+    float* __restrict__ o_rm = a.out2 + ((long)(b * 2 + 0) * a.d + c) * L;
+    float* __restrict__ o_cm = a.out2 + ((long)(b * 2 + 1) * a.d + c) * L;
+    float wk[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) wk[i] = a.w[c * 9 + i];
+    const float bias = a.bias ? a.bias[c] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int hl = ty + 8 * i;
+        const int h = h0 + hl, w = w0 + tx;
+        float y = 0.0f;
+        if (h < H && w < W) {
+            float t[9];
+            load_taps(plane, h, w, H, W, t);
+            float acc = bias;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) acc = fmaf(wk[k], t[k], acc);
+            y = acc * sigmoidf_fast(acc);
+            o_rm[(long)h * W + w] = y;
+        }
+        tile[hl][tx] = y;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int wl = ty + 8 * i;
+        const int w = w0 + wl, h = h0 + tx;
+        if (h < H && w < W) o_cm[(long)w * H + h] = tile[tx][wl];
+    }
+}
+
+__global__ void __launch_bounds__(256) dwconv_silu_bwd1_kernel(const DwArgs a) {
+    __shared__ float tile[kTile][kTile + 1];
+    __shared__ float red[4][10];
+    const int H = a.H, W = a.W;
+    const long L = (long)H * W;
+    const int tw = (W + kTile - 1) / kTile, th = (H + kTile - 1) / kTile;
+    const int plane_id = blockIdx.x / (tw * th);
+    const int tile_id = blockIdx.x - plane_id * (tw * th);
+    const int c = plane_id % a.d;
+    const int b = plane_id / a.d;
+    const int w0 = (tile_id % tw) * kTile, h0 = (tile_id / tw) * kTile;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float* __restrict__ plane = a.x + (long)plane_id * L;
+    const float* __restrict__ g_rm = a.g2 + ((long)(b * 2 + 0) * a.d + c) * L;
+    const float* __restrict__ g_cm = a.g2 + ((long)(b * 2 + 1) * a.d + c) * L;
+    float* __restrict__ gp = a.gpre + (long)plane_id * L;
+    // column-major gradient tile -> LDS, coalesced along h
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int wl = ty + 8 * i;
+        const int w = w0 + wl, h = h0 + tx;
+        tile[tx][wl] = (h < H && w < W) ? g_cm[(long)w * H + h] : 0.0f;
+    }
+    __syncthreads();
+    float wk[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) wk[i] = a.w[c * 9 + i];
+    const float bias = a.bias ? a.bias[c] : 0.0f;
+    float acc_w[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    float acc_b = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int hl = ty + 8 * i;
+        const int h = h0 + hl, w = w0 + tx;
+        if (h < H && w < W) {
+            float t[9];
+            load_taps(plane, h, w, H, W, t);
+            float pre = bias;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) pre = fmaf(wk[k], t[k], pre);
+            const float sg = sigmoidf_fast(pre);
+            const float dsilu = sg * fmaf(pre, 1.0f - sg, 1.0f);           // d/dp [p * sigmoid(p)]
+            const float g = (g_rm[(long)h * W + w] + tile[hl][tx]) * dsilu;
+            gp[(long)h * W + w] = g;
+            acc_b += g;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) acc_w[k] = fmaf(g, t[k], acc_w[k]);
+        }
+    }
+    // block reduction of the 10 per-channel sums, then one atomic each
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const float s = wave_sum_shfl(acc_w[k]);
+        if (lane == 0) red[wave][k] = s;
+    }
+    {
+        const float s = wave_sum_shfl(acc_b);
+        if (lane == 0) red[wave][9] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 10) {
+        const float s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        if (threadIdx.x < 9) atomicAdd(a.dw + c * 9 + threadIdx.x, s);
+        else if (a.dbias) atomicAdd(a.dbias + c, s);
+    }
+}
+
+__global__ void __launch_bounds__(256) dwconv_bwd2_kernel(const DwArgs a) {
+    const int H = a.H, W = a.W;
+    const long L = (long)H * W;
+    const int tw = (W + kTile - 1) / kTile, th = (H + kTile - 1) / kTile;
+    const int plane_id = blockIdx.x / (tw * th);
+    const int tile_id = blockIdx.x - plane_id * (tw * th);
+    const int c = plane_id % a.d;
+    const int w0 = (tile_id % tw) * kTile, h0 = (tile_id / tw) * kTile;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float* __restrict__ gp = a.gpre + (long)plane_id * L;
+    float* __restrict__ dx = a.dx + (long)plane_id * L;
+    float wk[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) wk[i] = a.w[c * 9 + i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int h = h0 + ty + 8 * i, w = w0 + tx;
+        if (h < H && w < W) {
+            float t[9];
+            load_taps(gp, h, w, H, W, t);      // t[dy*3+dx] = gpre[h+dy-1][w+dx-1]
+            // y[h'][w'] used x[h][w] with tap (h - h' + 1, w - w' + 1): dx[h][w] = sum_k W[8-k] * gpre tap k
+            float acc = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) acc = fmaf(wk[8 - k], t[k], acc);
+            dx[(long)h * W + w] = acc;
+        }
+    }
+}
+
+int check(const sigma_dwconv_params* p) {
+    if (!p) return SIGMA_OPS_ERR_ARG;
+    if (p->batch < 0 || p->channels <= 0 || p->height <= 0 || p->width <= 0) return SIGMA_OPS_ERR_ARG;
+    const long tiles = (long)((p->width + kTile - 1) / kTile) * ((p->height + kTile - 1) / kTile);
+    if ((long)p->batch * p->channels * tiles > 2147483647L) return SIGMA_OPS_ERR_ARG;
+    return SIGMA_OPS_OK;
+}
+
+dim3 grid_for(const sigma_dwconv_params* p) {
+    const long tiles = (long)((p->width + kTile - 1) / kTile) * ((p->height + kTile - 1) / kTile);
+    return dim3((unsigned)(tiles * p->batch * p->channels));
+}
+
+}  // namespace
+
+}  // namespace sigma
+
+extern "C" {
+
+int sigma_dwconv3x3_silu_fwd(const sigma_dwconv_params* p, void* stream) {
+    int rc = sigma::check(p);
+    if (rc) return rc;
+    if (p->batch == 0) return SIGMA_OPS_OK;
+    if (!p->x || !p->weight || !p->out2) return SIGMA_OPS_ERR_ARG;
+    sigma::DwArgs a{};
+    a.x = p->x; a.w = p->weight; a.bias = p->bias; a.out2 = p->out2;
+    a.B = p->batch; a.d = p->channels; a.H = p->height; a.W = p->width;
+    hipLaunchKernelGGL(sigma::dwconv_silu_fwd_kernel, sigma::grid_for(p), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    return hipGetLastError() == hipSuccess ? SIGMA_OPS_OK : SIGMA_OPS_ERR_LAUNCH;
+}
+
+int sigma_dwconv3x3_silu_bwd(const sigma_dwconv_params* p, void* stream) {
+    int rc = sigma::check(p);
+    if (rc) return rc;
+    if (p->batch == 0) return SIGMA_OPS_OK;
+    if (!p->x || !p->weight || !p->g2 || !p->gpre || !p->dweight || !p->dx) return SIGMA_OPS_ERR_ARG;
+    sigma::DwArgs a{};
+    a.x = p->x; a.w = p->weight; a.bias = p->bias; a.g2 = p->g2; a.gpre = p->gpre;
+    a.dw = p->dweight; a.dbias = p->dbias; a.dx = p->dx;
+    a.B = p->batch; a.d = p->channels; a.H = p->height; a.W = p->width;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(sigma::dwconv_silu_bwd1_kernel, sigma::grid_for(p), dim3(256), 0, s, a);
+    if (hipGetLastError() != hipSuccess) return SIGMA_OPS_ERR_LAUNCH;
+    hipLaunchKernelGGL(sigma::dwconv_bwd2_kernel, sigma::grid_for(p), dim3(256), 0, s, a);
+    return hipGetLastError() == hipSuccess ? SIGMA_OPS_OK : SIGMA_OPS_ERR_LAUNCH;
+}
+
+}  // extern "C"

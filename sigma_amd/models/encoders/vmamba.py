@@ -31,7 +31,7 @@ import torch.nn.functional as F
 import os
 
 from ...selective_scan import selective_scan_fn
-from ...ss2d_fused import ss2d_core
+from ...ss2d_fused import dwconv_silu_two_orders, ss2d_core, ss2d_core_from_orders
 
 # SIGMA_SS2D_FUSED=0 selects the plain-autograd formulation of SS2D's core (A/B measurements and
 # the fused-vs-unfused parity test); both run the same HIP scan kernels.
@@ -135,7 +135,7 @@ def ss2d_scan(x: torch.Tensor, x_proj_weight, dt_projs_weight, dt_projs_bias, A_
       k=0 row-major, k=1 column-major, k=2 reversed row-major, k=3 reversed column-major.
     """
     B, d, H, W = x.shape
-    if _FUSED_SS2D:
+    if _FUSED_SS2D and x.is_cuda:          # CPU tensors take the plain formulation, whose scan raises (no fallback)
         y = ss2d_core(x, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds)     # (B, d, L)
         return out_norm(y.transpose(1, 2).reshape(B, H, W, d)).to(x.dtype)
     K, c, _ = x_proj_weight.shape                # c = R + 2N
@@ -197,9 +197,17 @@ class SS2D(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:       # x: (B, H, W, C)
         xz = self.in_proj(x)
         xi, z = xz.chunk(2, dim=-1)
-        xi = self.act(self.conv2d(xi.permute(0, 3, 1, 2).contiguous()))      # (B, d, H, W)
-        y = ss2d_scan(xi, self.x_proj_weight, self.dt_projs_weight, self.dt_projs_bias, self.A_logs, self.Ds,
-                      self.out_norm)
+        xi = xi.permute(0, 3, 1, 2).contiguous()                             # (B, d, H, W)
+        if _FUSED_SS2D and xi.is_cuda:
+            # depthwise conv + SiLU + both scan orders in one HIP pass, then the fused scan core
+            Bq, dq, Hq, Wq = xi.shape
+            xs2 = dwconv_silu_two_orders(xi, self.conv2d.weight, self.conv2d.bias)
+            y = ss2d_core_from_orders(xs2, Hq, Wq, self.x_proj_weight, self.dt_projs_weight, self.dt_projs_bias,
+                                      self.A_logs, self.Ds)
+            y = self.out_norm(y.transpose(1, 2).reshape(Bq, Hq, Wq, dq)).to(x.dtype)
+        else:
+            y = ss2d_scan(self.act(self.conv2d(xi)), self.x_proj_weight, self.dt_projs_weight, self.dt_projs_bias,
+                          self.A_logs, self.Ds, self.out_norm)
         y = y * F.silu(z)
         return self.dropout(self.out_proj(y))
 

@@ -45,21 +45,79 @@ def _two_orders(x4: torch.Tensor) -> torch.Tensor:
     return out
 
 
-class SS2DCoreFn(torch.autograd.Function):
-    """y = CrossMerge(selective_scan(CrossScan(x), ...)) for x (B, d, H, W) -> y (B, d, H*W)."""
+class DwConvSiLUTwoOrdersFn(torch.autograd.Function):
+    """xs2 = [silu(dwconv3x3(x)) row-major, the same column-major]  (B, d, H, W) -> (B, 2, d, H*W).
+
+    Reference: SS2D.forward vmamba.py:1075-1077 + the layout half of CrossScan (:80-89); kernels in
+    sigma_amd/csrc/dwconv.hip, C ABI in include/sigma_ops.h."""
 
     @staticmethod
-    def forward(ctx, x, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds):
+    def forward(ctx, x, weight, bias):
+        import ctypes
+        from . import _capi
+        lib = _capi.load()
+        if not x.is_cuda:
+            raise RuntimeError("dwconv3x3_silu: GPU tensors only (no fallback)")
+        x = x.float().contiguous()
+        w = weight.float().contiguous()
+        b = None if bias is None else bias.float().contiguous()
         B, d, H, W = x.shape
-        L = H * W
+        if tuple(w.shape) != (d, 1, 3, 3):
+            raise RuntimeError("dwconv3x3_silu: weight must be (d, 1, 3, 3)")
+        out2 = torch.empty(B, 2, d, H * W, device=x.device, dtype=torch.float32)
+        p = _capi.DwConvParams()
+        p.batch, p.channels, p.height, p.width = B, d, H, W
+        p.x, p.weight, p.bias, p.out2 = x.data_ptr(), w.data_ptr(), (b.data_ptr() if b is not None else None), out2.data_ptr()
+        with torch.cuda.device(x.device):
+            _capi.check(lib.sigma_dwconv3x3_silu_fwd(ctypes.byref(p), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                        "dwconv3x3_silu_fwd")
+        ctx.save_for_backward(x, w, b if b is not None else x.new_empty(0))
+        ctx.has_bias = b is not None
+        return out2
+
+    @staticmethod
+    def backward(ctx, g2):
+        import ctypes
+        from . import _capi
+        lib = _capi.load()
+        x, w, b = ctx.saved_tensors
+        B, d, H, W = x.shape
+        g2 = g2.float().contiguous()
+        gpre = torch.empty_like(x)
+        dx = torch.empty_like(x)
+        dw = torch.zeros_like(w)
+        db = torch.zeros(d, device=x.device, dtype=torch.float32) if ctx.has_bias else None
+        p = _capi.DwConvParams()
+        p.batch, p.channels, p.height, p.width = B, d, H, W
+        p.x, p.weight, p.bias = x.data_ptr(), w.data_ptr(), (b.data_ptr() if ctx.has_bias else None)
+        p.g2, p.gpre, p.dweight, p.dx = g2.data_ptr(), gpre.data_ptr(), dw.data_ptr(), dx.data_ptr()
+        p.dbias = db.data_ptr() if db is not None else None
+        with torch.cuda.device(x.device):
+            _capi.check(lib.sigma_dwconv3x3_silu_bwd(ctypes.byref(p), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                        "dwconv3x3_silu_bwd")
+        return dx, dw, db
+
+
+def dwconv_silu_two_orders(x, weight, bias):
+    return DwConvSiLUTwoOrdersFn.apply(x, weight, bias)
+
+
+class SS2DCoreFn(torch.autograd.Function):
+    """y = CrossMerge(selective_scan(CrossScan(x), ...)); input xs2 = [row-major, column-major]
+    sequences of x, (B, 2, d, H*W) -> y (B, d, H*W)."""
+
+    @staticmethod
+    def forward(ctx, xs2, H, W, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds):
+        B, _, d, L = xs2.shape
+        if L != H * W:
+            raise RuntimeError("SS2DCoreFn: xs2 must be (B, 2, d, H*W)")
         K, c, _ = x_proj_weight.shape
         R = dt_projs_weight.shape[2]
         N = A_logs.shape[1]
         if K != 4:
             raise RuntimeError("SS2DCoreFn expects the 4-direction parameter stack")
-        x = x.float()
+        xs2 = xs2.float().contiguous()
         perm = list(_PERM)
-        xs2 = _two_orders(x)                                                   # (B, 2, d, L)
         Wst = x_proj_weight.float()[perm].reshape(2, 2 * c, d)                 # [order j][(flip i, row)][d]
         p4 = torch.matmul(Wst.unsqueeze(0), xs2).view(B, 4, c, L)              # == (B, group g, R+2N, L)
         dtw = dt_projs_weight.float()[perm]                                    # (4, d, R)
@@ -102,14 +160,35 @@ class SS2DCoreFn(torch.autograd.Function):
         dxs2 += du4[:, :, 0]
         dxs2 += du4[:, :, 1]
         dWst = torch.matmul(dp2, xs2.transpose(-1, -2)).sum(0)                 # (2, 2c, d)
-        dx = dxs2[:, 0].reshape(B, d, H, W) + dxs2[:, 1].view(B, d, W, H).transpose(2, 3)
         d_xproj = dWst.view(4, c, d)[perm]
         d_dtw = d_dtw[perm]
         dA_logs = (dA * A).view(4, d, N)[perm].reshape(4 * d, N)               # A = -exp(A_logs)
         dDs = dD.view(4, d)[perm].reshape(-1)
         dbias = dbias.view(4, d)[perm]
-        return dx, d_xproj, d_dtw, dbias, dA_logs, dDs
+        return dxs2, None, None, d_xproj, d_dtw, dbias, dA_logs, dDs
+
+
+class _TwoOrdersFn(torch.autograd.Function):
+    """(B, d, H, W) -> (B, 2, d, L) and its adjoint, with plain copies (callers without the fused conv)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.hw = x.shape[2:]
+        return _two_orders(x.float())
+
+    @staticmethod
+    def backward(ctx, g):
+        H, W = ctx.hw
+        B, _, d, L = g.shape
+        return g[:, 0].reshape(B, d, H, W) + g[:, 1].reshape(B, d, W, H).transpose(2, 3)
 
 
 def ss2d_core(x, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds):
-    return SS2DCoreFn.apply(x, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds)
+    """x (B, d, H, W) -> (B, d, H*W)"""
+    B, d, H, W = x.shape
+    return SS2DCoreFn.apply(_TwoOrdersFn.apply(x), H, W, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds)
+
+
+def ss2d_core_from_orders(xs2, H, W, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds):
+    """xs2 (B, 2, d, H*W) as produced by dwconv_silu_two_orders -> (B, d, H*W)"""
+    return SS2DCoreFn.apply(xs2, H, W, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds)

@@ -24,6 +24,11 @@ def test_exports_every_declared_symbol():
     lib = _capi.load()
     for name in declared:
         assert getattr(lib, name) is not None
+    ops = open(os.path.join(ROOT, "include", "sigma_ops.h")).read()
+    declared_ops = set(re.findall(r"^\s*int\s+(sigma_\w+)\s*\(", ops, flags=re.M))
+    assert declared_ops == set(_capi.OPS_SYMBOLS), declared_ops ^ set(_capi.OPS_SYMBOLS)
+    for name in declared_ops:
+        assert getattr(lib, name) is not None
 
 
 def test_struct_layout_matches_header(tmp_path):
@@ -31,16 +36,18 @@ def test_struct_layout_matches_header(tmp_path):
     ctypes mirror in sigma_amd/_capi.py."""
     import subprocess
     lines = []
-    for cname, cls in (("sigma_scan_fwd_params", _capi.FwdParams), ("sigma_scan_bwd_params", _capi.BwdParams)):
+    structs = (("sigma_scan_fwd_params", _capi.FwdParams), ("sigma_scan_bwd_params", _capi.BwdParams),
+               ("sigma_dwconv_params", _capi.DwConvParams))
+    for cname, cls in structs:
         lines.append(f'printf("%s %zu\\n", "{cname}", sizeof({cname}));')
         for fname, _ in cls._fields_:
             lines.append(f'printf("%s.%s %zu\\n", "{cname}", "{fname}", offsetof({cname}, {fname}));')
     src = tmp_path / "layout.c"
-    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "sigma_scan.h"\nint main(void){' + "".join(lines) + "return 0;}")
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "sigma_scan.h"\n#include "sigma_ops.h"\nint main(void){' + "".join(lines) + "return 0;}")
     exe = tmp_path / "layout"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     got = dict(l.split() for l in subprocess.check_output([str(exe)], text=True).splitlines())
-    for cname, cls in (("sigma_scan_fwd_params", _capi.FwdParams), ("sigma_scan_bwd_params", _capi.BwdParams)):
+    for cname, cls in structs:
         assert int(got[cname]) == ctypes.sizeof(cls)
         for fname, _ in cls._fields_:
             assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, fname

@@ -97,3 +97,30 @@ def test_fused_ss2d_core_equals_plain_autograd_formulation(shape):
     for n, a, b in zip(names, res[True], res[False]):
         scale = float(b.abs().max()) + 1e-6
         assert float((a - b).abs().max()) <= 2e-4 * scale + 1e-5, (n, float((a - b).abs().max()), scale)
+
+
+@pytest.mark.parametrize("shape", [(2, 24, 15, 20), (1, 7, 33, 65), (3, 16, 120, 160), (2, 5, 1, 9), (1, 3, 46, 80)])
+def test_dwconv_silu_two_orders_matches_torch(shape):
+    """HIP depthwise 3x3 conv + SiLU + both scan orders (include/sigma_ops.h) vs nn.Conv2d + F.silu +
+    view/transpose in plain torch (vmamba.py:1075-1077, 80-89): values, dx, dW, dbias."""
+    import torch.nn.functional as F
+    from sigma_amd.ss2d_fused import dwconv_silu_two_orders
+    B, d, H, W = shape
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(B, d, H, W, generator=g).cuda()
+    w = (0.4 * torch.randn(d, 1, 3, 3, generator=g)).cuda()
+    b = (0.2 * torch.randn(d, generator=g)).cuda()
+    gy = torch.randn(B, 2, d, H * W, generator=g).cuda()
+    res = []
+    for fused in (True, False):
+        xi, wi, bi = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+        if fused:
+            out = dwconv_silu_two_orders(xi, wi, bi)
+        else:
+            y = F.silu(F.conv2d(xi, wi, bi, padding=1, groups=d))
+            out = torch.stack([y.reshape(B, d, H * W), y.transpose(2, 3).reshape(B, d, H * W)], dim=1)
+        out.backward(gy)
+        res.append([out.detach(), xi.grad, wi.grad, bi.grad])
+    for n, a, r in zip(["out", "dx", "dw", "db"], res[0], res[1]):
+        scale = float(r.abs().max()) + 1e-6
+        assert float((a - r).abs().max()) <= 3e-5 * scale + 1e-6 * (H * W * B) ** 0.5, (n, float((a - r).abs().max()), scale)
