@@ -32,14 +32,18 @@ enum sigma_ops_status {
 
 typedef struct sigma_dwconv_params {
     int32_t batch, channels, height, width;
+    int32_t n_orders;      /* 2: out2/g2 hold the row-major AND the column-major sequence (SS2D);
+                              1: row-major only, i.e. plain conv + SiLU (CroMB / ConMB, vmamba.py:1629-1630,
+                              1262-1263) */
+    int32_t reserved_;
     const float *x;        /* (B, d, H, W)   input of the convolution                              */
     const float *weight;   /* (d, 1, 3, 3)                                                         */
     const float *bias;     /* (d) or NULL                                                          */
     /* forward */
-    float *out2;           /* (B, 2, d, H*W): [:,0] = silu(conv(x)) row-major, [:,1] = the same
+    float *out2;           /* (B, n_orders, d, H*W): [:,0] = silu(conv(x)) row-major, [:,1] = the same
                               image in column-major order (index w*H + h)                          */
     /* backward */
-    const float *g2;       /* (B, 2, d, H*W) gradient of out2                                      */
+    const float *g2;       /* (B, n_orders, d, H*W) gradient of out2                                      */
     float *gpre;           /* (B, d, H, W) scratch: gradient w.r.t. the pre-activation            */
     float *dweight;        /* (d, 1, 3, 3) ACCUMULATED into (caller zeroes)                        */
     float *dbias;          /* (d) ACCUMULATED into, or NULL                                        */

@@ -66,6 +66,7 @@ class DwConvParams(ctypes.Structure):
     """mirror of sigma_dwconv_params (include/sigma_ops.h)"""
     _fields_ = [
         ("batch", ctypes.c_int32), ("channels", ctypes.c_int32), ("height", ctypes.c_int32), ("width", ctypes.c_int32),
+        ("n_orders", ctypes.c_int32), ("reserved_", ctypes.c_int32),
         ("x", ctypes.c_void_p), ("weight", ctypes.c_void_p), ("bias", ctypes.c_void_p),
         ("out2", ctypes.c_void_p),
         ("g2", ctypes.c_void_p), ("gpre", ctypes.c_void_p), ("dweight", ctypes.c_void_p), ("dbias", ctypes.c_void_p),

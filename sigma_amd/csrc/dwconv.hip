@@ -32,7 +32,7 @@ struct DwArgs {
     float* gpre;            // bwd1 out / bwd2 in: (B, d, H, W)
     float* dw; float* dbias;   // (d, 9), (d): accumulated
     float* dx;              // bwd2 out: (B, d, H, W)
-    int B, d, H, W;
+    int B, d, H, W, orders;
 };
 
 __device__ __forceinline__ float sigmoidf_fast(float v) {
@@ -71,8 +71,8 @@ __global__ void __launch_bounds__(256) dwconv_silu_fwd_kernel(const DwArgs a) {
     const int w0 = (tile_id % tw) * kTile, h0 = (tile_id / tw) * kTile;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const float* __restrict__ plane = a.x + (long)plane_id * L;
-    float* __restrict__ o_rm = a.out2 + ((long)(b * 2 + 0) * a.d + c) * L;
-    float* __restrict__ o_cm = a.out2 + ((long)(b * 2 + 1) * a.d + c) * L;
+    float* __restrict__ o_rm = a.out2 + ((long)(b * a.orders + 0) * a.d + c) * L;
+    float* __restrict__ o_cm = a.out2 + ((long)(b * a.orders + 1) * a.d + c) * L;
     float wk[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) wk[i] = a.w[c * 9 + i];
@@ -93,6 +93,7 @@ __global__ void __launch_bounds__(256) dwconv_silu_fwd_kernel(const DwArgs a) {
         }
         tile[hl][tx] = y;
     }
+    if (a.orders < 2) return;
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -115,15 +116,15 @@ __global__ void __launch_bounds__(256) dwconv_silu_bwd1_kernel(const DwArgs a) {
     const int w0 = (tile_id % tw) * kTile, h0 = (tile_id / tw) * kTile;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const float* __restrict__ plane = a.x + (long)plane_id * L;
-    const float* __restrict__ g_rm = a.g2 + ((long)(b * 2 + 0) * a.d + c) * L;
-    const float* __restrict__ g_cm = a.g2 + ((long)(b * 2 + 1) * a.d + c) * L;
+    const float* __restrict__ g_rm = a.g2 + ((long)(b * a.orders + 0) * a.d + c) * L;
+    const float* __restrict__ g_cm = a.g2 + ((long)(b * a.orders + 1) * a.d + c) * L;
     float* __restrict__ gp = a.gpre + (long)plane_id * L;
     // column-major gradient tile -> LDS, coalesced along h
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int wl = ty + 8 * i;
         const int w = w0 + wl, h = h0 + tx;
-        tile[tx][wl] = (h < H && w < W) ? g_cm[(long)w * H + h] : 0.0f;
+        tile[tx][wl] = (a.orders > 1 && h < H && w < W) ? g_cm[(long)w * H + h] : 0.0f;
     }
     __syncthreads();
     float wk[9];
@@ -202,6 +203,7 @@ __global__ void __launch_bounds__(256) dwconv_bwd2_kernel(const DwArgs a) {
 int check(const sigma_dwconv_params* p) {
     if (!p) return SIGMA_OPS_ERR_ARG;
     if (p->batch < 0 || p->channels <= 0 || p->height <= 0 || p->width <= 0) return SIGMA_OPS_ERR_ARG;
+    if (p->n_orders != 1 && p->n_orders != 2) return SIGMA_OPS_ERR_ARG;
     const long tiles = (long)((p->width + kTile - 1) / kTile) * ((p->height + kTile - 1) / kTile);
     if ((long)p->batch * p->channels * tiles > 2147483647L) return SIGMA_OPS_ERR_ARG;
     return SIGMA_OPS_OK;
@@ -225,7 +227,7 @@ int sigma_dwconv3x3_silu_fwd(const sigma_dwconv_params* p, void* stream) {
     if (!p->x || !p->weight || !p->out2) return SIGMA_OPS_ERR_ARG;
     sigma::DwArgs a{};
     a.x = p->x; a.w = p->weight; a.bias = p->bias; a.out2 = p->out2;
-    a.B = p->batch; a.d = p->channels; a.H = p->height; a.W = p->width;
+    a.B = p->batch; a.d = p->channels; a.H = p->height; a.W = p->width; a.orders = p->n_orders;
     hipLaunchKernelGGL(sigma::dwconv_silu_fwd_kernel, sigma::grid_for(p), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     return hipGetLastError() == hipSuccess ? SIGMA_OPS_OK : SIGMA_OPS_ERR_LAUNCH;
 }
@@ -238,7 +240,7 @@ int sigma_dwconv3x3_silu_bwd(const sigma_dwconv_params* p, void* stream) {
     sigma::DwArgs a{};
     a.x = p->x; a.w = p->weight; a.bias = p->bias; a.g2 = p->g2; a.gpre = p->gpre;
     a.dw = p->dweight; a.dbias = p->dbias; a.dx = p->dx;
-    a.B = p->batch; a.d = p->channels; a.H = p->height; a.W = p->width;
+    a.B = p->batch; a.d = p->channels; a.H = p->height; a.W = p->width; a.orders = p->n_orders;
     hipStream_t s = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(sigma::dwconv_silu_bwd1_kernel, sigma::grid_for(p), dim3(256), 0, s, a);
     if (hipGetLastError() != hipSuccess) return SIGMA_OPS_ERR_LAUNCH;

@@ -31,7 +31,7 @@ import torch.nn.functional as F
 import os
 
 from ...selective_scan import selective_scan_fn
-from ...ss2d_fused import dwconv_silu_two_orders, ss2d_core, ss2d_core_from_orders
+from ...ss2d_fused import dwconv_silu, dwconv_silu_two_orders, ss2d_core, ss2d_core_from_orders
 
 # SIGMA_SS2D_FUSED=0 selects the plain-autograd formulation of SS2D's core (A/B measurements and
 # the fused-vs-unfused parity test); both run the same HIP scan kernels.
@@ -123,6 +123,14 @@ def _stacked_ssm_params(mod: nn.Module, K: int, d_inner: int, d_state: int, dt_r
     mod.dt_projs_bias = nn.Parameter(torch.stack([t.bias.detach() for t in dts], dim=0))
     mod.A_logs = _a_log(d_state, d_inner, copies=K)
     mod.Ds = _d_skip(d_inner, copies=K)
+
+
+def _conv_act(conv: nn.Conv2d, act: nn.Module, x: torch.Tensor) -> torch.Tensor:
+    """act(conv(x)) for the depthwise 3x3 + SiLU pairs of the Mamba blocks: one HIP pass on the GPU
+    (sigma_amd/csrc/dwconv.hip); the torch modules otherwise (CPU host-logic tests)."""
+    if _FUSED_SS2D and x.is_cuda and isinstance(act, nn.SiLU) and conv.kernel_size == (3, 3) and conv.groups == conv.in_channels:
+        return dwconv_silu(x, conv.weight, conv.bias)
+    return act(conv(x))
 
 
 # --------------------------------------------------------------------------- SS2D core
@@ -366,7 +374,7 @@ class CrossMambaFusion_SS2D_SSM(nn.Module):
     def forward(self, x_rgb: torch.Tensor, x_e: torch.Tensor):   # (B, H, W, C) each
         B, H, W, _ = x_rgb.shape
         both = torch.cat([self.in_proj(x_rgb), self.in_proj_modalx(x_e)], dim=0)      # shared conv: one launch
-        both = self.act(self.conv2d(both.permute(0, 3, 1, 2).contiguous())).flatten(2)  # (2B, d, L)
+        both = _conv_act(self.conv2d, self.act, both.permute(0, 3, 1, 2).contiguous()).flatten(2)  # (2B, d, L)
         y_rgb, y_e = self.CMA_ssm(both[:B], both[B:])
         y_rgb = self.dropout_rgb(self.out_proj_rgb(y_rgb.view(B, H, W, -1)))
         y_e = self.dropout_e(self.out_proj_e(y_e.view(B, H, W, -1)))
@@ -448,7 +456,7 @@ class ConMB_SS2D(nn.Module):
     def forward(self, x_rgb: torch.Tensor, x_e: torch.Tensor) -> torch.Tensor:   # (B, H, W, C) each
         p_rgb = self.in_proj(x_rgb).permute(0, 3, 1, 2).contiguous()             # (B, d, H, W)
         p_e = self.in_proj_modalx(x_e).permute(0, 3, 1, 2).contiguous()
-        y_rgb, y_e = self._scan(self.act(self.conv2d(p_rgb)), self.act(self.conv2d_modalx(p_e)))
+        y_rgb, y_e = self._scan(_conv_act(self.conv2d, self.act, p_rgb), _conv_act(self.conv2d_modalx, self.act, p_e))
         # squeeze/excite: each modality is gated by the OTHER modality's pooled in_proj output (:1271-1281)
         g_rgb = self.fc1(p_rgb.mean(dim=(2, 3)))                                 # (B, d)
         g_e = self.fc2(p_e.mean(dim=(2, 3)))

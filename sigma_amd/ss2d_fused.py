@@ -52,7 +52,7 @@ class DwConvSiLUTwoOrdersFn(torch.autograd.Function):
     sigma_amd/csrc/dwconv.hip, C ABI in include/sigma_ops.h."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
+    def forward(ctx, x, weight, bias, n_orders=2):
         import ctypes
         from . import _capi
         lib = _capi.load()
@@ -64,9 +64,10 @@ class DwConvSiLUTwoOrdersFn(torch.autograd.Function):
         B, d, H, W = x.shape
         if tuple(w.shape) != (d, 1, 3, 3):
             raise RuntimeError("dwconv3x3_silu: weight must be (d, 1, 3, 3)")
-        out2 = torch.empty(B, 2, d, H * W, device=x.device, dtype=torch.float32)
+        out2 = torch.empty(B, n_orders, d, H * W, device=x.device, dtype=torch.float32)
+        ctx.n_orders = n_orders
         p = _capi.DwConvParams()
-        p.batch, p.channels, p.height, p.width = B, d, H, W
+        p.batch, p.channels, p.height, p.width, p.n_orders = B, d, H, W, n_orders
         p.x, p.weight, p.bias, p.out2 = x.data_ptr(), w.data_ptr(), (b.data_ptr() if b is not None else None), out2.data_ptr()
         with torch.cuda.device(x.device):
             _capi.check(lib.sigma_dwconv3x3_silu_fwd(ctypes.byref(p), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
@@ -88,18 +89,24 @@ class DwConvSiLUTwoOrdersFn(torch.autograd.Function):
         dw = torch.zeros_like(w)
         db = torch.zeros(d, device=x.device, dtype=torch.float32) if ctx.has_bias else None
         p = _capi.DwConvParams()
-        p.batch, p.channels, p.height, p.width = B, d, H, W
+        p.batch, p.channels, p.height, p.width, p.n_orders = B, d, H, W, ctx.n_orders
         p.x, p.weight, p.bias = x.data_ptr(), w.data_ptr(), (b.data_ptr() if ctx.has_bias else None)
         p.g2, p.gpre, p.dweight, p.dx = g2.data_ptr(), gpre.data_ptr(), dw.data_ptr(), dx.data_ptr()
         p.dbias = db.data_ptr() if db is not None else None
         with torch.cuda.device(x.device):
             _capi.check(lib.sigma_dwconv3x3_silu_bwd(ctypes.byref(p), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
                         "dwconv3x3_silu_bwd")
-        return dx, dw, db
+        return dx, dw, db, None
 
 
 def dwconv_silu_two_orders(x, weight, bias):
-    return DwConvSiLUTwoOrdersFn.apply(x, weight, bias)
+    return DwConvSiLUTwoOrdersFn.apply(x, weight, bias, 2)
+
+
+def dwconv_silu(x, weight, bias):
+    """silu(depthwise conv3x3(x) + bias), (B, d, H, W) -> (B, d, H, W); HIP kernel, GPU tensors only."""
+    B, d, H, W = x.shape
+    return DwConvSiLUTwoOrdersFn.apply(x, weight, bias, 1).view(B, d, H, W)
 
 
 class SS2DCoreFn(torch.autograd.Function):

@@ -104,7 +104,7 @@ def test_dwconv_silu_two_orders_matches_torch(shape):
     """HIP depthwise 3x3 conv + SiLU + both scan orders (include/sigma_ops.h) vs nn.Conv2d + F.silu +
     view/transpose in plain torch (vmamba.py:1075-1077, 80-89): values, dx, dW, dbias."""
     import torch.nn.functional as F
-    from sigma_amd.ss2d_fused import dwconv_silu_two_orders
+    from sigma_amd.ss2d_fused import dwconv_silu, dwconv_silu_two_orders
     B, d, H, W = shape
     g = torch.Generator().manual_seed(0)
     x = torch.randn(B, d, H, W, generator=g).cuda()
@@ -121,6 +121,15 @@ def test_dwconv_silu_two_orders_matches_torch(shape):
             out = torch.stack([y.reshape(B, d, H * W), y.transpose(2, 3).reshape(B, d, H * W)], dim=1)
         out.backward(gy)
         res.append([out.detach(), xi.grad, wi.grad, bi.grad])
-    for n, a, r in zip(["out", "dx", "dw", "db"], res[0], res[1]):
+    # single-order variant (CroMB / ConMB): same conv + SiLU, row-major only
+    xi, wi, bi = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    y1 = dwconv_silu(xi, wi, bi)
+    y1.backward(gy[:, 0].reshape(B, d, H, W))
+    xr, wr, br = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+    yr = F.silu(F.conv2d(xr, wr, br, padding=1, groups=d))
+    yr.backward(gy[:, 0].reshape(B, d, H, W))
+    res[0] += [y1.detach(), xi.grad, wi.grad, bi.grad]
+    res[1] += [yr.detach(), xr.grad, wr.grad, br.grad]
+    for n, a, r in zip(["out", "dx", "dw", "db", "out1", "dx1", "dw1", "db1"], res[0], res[1]):
         scale = float(r.abs().max()) + 1e-6
         assert float((a - r).abs().max()) <= 3e-5 * scale + 1e-6 * (H * W * B) ** 0.5, (n, float((a - r).abs().max()), scale)
