@@ -161,11 +161,19 @@ Plan plan_fwd(const sigma_scan_fwd_params* p, bool vec) {
             while (NB > 1 && sigma::fwd_lds_bytes(pl.items, R, W, NB, p->dstate) > kLdsLimit) NB >>= 1;
             if (sigma::fwd_lds_bytes(pl.items, R, W, NB, p->dstate) > kLdsLimit) continue;
             const long nwg = total_rows / R;
-            const long rounds = (nwg + kCUs - 1) / kCUs;
             const int nsuper = (ntiles + W - 1) / W;
-            const double waves = (double)R * W;
+            const int waves = R * W;
+            // two 8-wave workgroups share a CU (<= 128 VGPRs, ~40 KB LDS each): their barriers and
+            // staging waits interleave, measured 12-25 % faster than one 16-wave workgroup
+            const size_t lds = sigma::fwd_lds_bytes(pl.items, R, W, NB, p->dstate);
+            int wgpc = 16 / waves;
+            if ((size_t)wgpc * lds > kLdsLimit) wgpc = (int)(kLdsLimit / lds);
+            if (wgpc < 1) wgpc = 1;
+            if (wgpc > 2) wgpc = 2;
+            const long rounds = (nwg + (long)kCUs * wgpc - 1) / ((long)kCUs * wgpc);
             // a CU with few waves runs each of them faster, but not proportionally
-            const double per_step = (0.35 + 0.65 * waves / maxw) * (1.0 + 2.0 / R + (W > 1 ? 0.15 : 0.0));
+            const double per_step = (0.35 + 0.65 * (double)(waves * wgpc) / 16.0) *
+                                    (1.0 + 2.0 / R + (W > 1 ? 0.15 : 0.0)) * (wgpc >= 2 ? 0.85 : 1.0);
             const double cost = (double)rounds * nsuper * per_step;
             if (cost < best) { best = cost; pl.rows = R; pl.tiles = W; pl.nb = NB; }
         }
@@ -194,9 +202,13 @@ Plan plan_bwd(const sigma_scan_fwd_params* p, bool vec) {
         if (rpg % R != 0) continue;
         if (fr > 0 && R != fr && rpg % fr == 0 && fr <= maxw) continue;   // forced rows (when legal)
         if (sigma::bwd_lds_bytes(pl.items, R, NB, p->dstate) > kLdsLimit) continue;
+        // measured (tools/scan_bench.py --sweep): with enough rows the largest workgroup wins (B/C
+        // staging and the dB/dC column sums are per-workgroup costs); with few rows 8 rows per
+        // workgroup beat both 3 (fixed costs dominate) and 12 (too few workgroups)
         const long nwg = total_rows / R;
-        const long rounds = (nwg + kCUs - 1) / kCUs;
-        const double cost = (double)rounds * (0.35 + 0.65 * R / maxw) * (1.0 + 0.5 / R);
+        const bool many = total_rows / maxw >= kCUs;
+        const double cost = many ? (double)(maxw - R) : (R <= 8 ? (double)(8 - R) : 100.0 + R);
+        (void)nwg;
         if (cost < best) { best = cost; pl.rows = R; }
     }
     pl.grid = (int)(total_rows / pl.rows);
