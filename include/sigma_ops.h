@@ -53,6 +53,24 @@ typedef struct sigma_dwconv_params {
 int sigma_dwconv3x3_silu_fwd(const sigma_dwconv_params *params, void *stream);
 int sigma_dwconv3x3_silu_bwd(const sigma_dwconv_params *params, void *stream);
 
+/*   sigma_cross_merge_nhwc / sigma_cross_split_nhwc
+ *       CrossMerge (vmamba.py:100-108) + the transpose to channels-last in front of out_norm
+ *       (vmamba.py:221-224), and its adjoint (CrossMerge.backward = CrossScan, vmamba.py:110-121).
+ *       The scan kernels already deliver the flipped directions in natural order, so with the group
+ *       order g = 2 * memory_order + flipped:
+ *           merge:  nhwc[b,h,w,c] = planes4[b,0,c,hW+w] + planes4[b,1,c,hW+w]
+ *                                 + planes4[b,2,c,wH+h] + planes4[b,3,c,wH+h]
+ *           split:  planes2[b,0,c,hW+w] = planes2[b,1,c,wH+h] = nhwc[b,h,w,c]                      */
+typedef struct sigma_merge_params {
+    int32_t batch, channels, height, width;
+    const float *planes4;  /* merge in : (B, 4, d, H*W)                       */
+    float *planes2;        /* split out: (B, 2, d, H*W)                       */
+    float *nhwc;           /* merge out / split in: (B, H, W, d) contiguous   */
+} sigma_merge_params;
+
+int sigma_cross_merge_nhwc(const sigma_merge_params *params, void *stream);
+int sigma_cross_split_nhwc(const sigma_merge_params *params, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -74,8 +74,16 @@ class DwConvParams(ctypes.Structure):
     ]
 
 
+class MergeParams(ctypes.Structure):
+    """mirror of sigma_merge_params (include/sigma_ops.h)"""
+    _fields_ = [
+        ("batch", ctypes.c_int32), ("channels", ctypes.c_int32), ("height", ctypes.c_int32), ("width", ctypes.c_int32),
+        ("planes4", ctypes.c_void_p), ("planes2", ctypes.c_void_p), ("nhwc", ctypes.c_void_p),
+    ]
+
+
 # every symbol include/sigma_ops.h declares
-OPS_SYMBOLS = ("sigma_dwconv3x3_silu_fwd", "sigma_dwconv3x3_silu_bwd")
+OPS_SYMBOLS = ("sigma_dwconv3x3_silu_fwd", "sigma_dwconv3x3_silu_bwd", "sigma_cross_merge_nhwc", "sigma_cross_split_nhwc")
 
 # every symbol include/sigma_scan.h declares; tests check the library exports all of them
 EXPORTED_SYMBOLS = (
@@ -130,7 +138,7 @@ def load() -> ctypes.CDLL:
     lib.sigma_scan_selftest.restype = ctypes.c_int
     for name in OPS_SYMBOLS:
         fn = getattr(lib, name)
-        fn.argtypes = [P(DwConvParams), ctypes.c_void_p]
+        fn.argtypes = [P(MergeParams if "cross_" in name else DwConvParams), ctypes.c_void_p]
         fn.restype = ctypes.c_int
     if lib.sigma_scan_abi_version() != SIGMA_SCAN_ABI_VERSION:
         raise SigmaHipUnavailable(

@@ -1,0 +1,150 @@
+// merge.hip -- CrossMerge and its adjoint as single passes between the scan's (B, G, d, L) planes and the
+// channels-last (B, H, W, d) activations the rest of SS2D works in.
+//
+// Reference: CrossMerge.forward (models/encoders/vmamba.py:100-108) followed by
+//   y = y.transpose(dim0=1, dim1=2).contiguous(); y = out_norm(y).view(B, H, W, -1)     (vmamba.py:221-224)
+// and, in backward, CrossMerge.backward = CrossScan (vmamba.py:110-121) applied to the transposed gradient.
+// With the flipped directions already written in natural order by the scan kernels (sigma_scan.h,
+// rev_group_mask), the merge is
+//   y[b, h, w, c] = ys[b,0,c,hW+w] + ys[b,1,c,hW+w] + ys[b,2,c,wH+h] + ys[b,3,c,wH+h]
+// and its adjoint writes the gradient once in each memory order:
+//   g2[b,0,c,hW+w] = g2[b,1,c,wH+h] = dy[b, h, w, c].
+// Both are 3-D transposes (channel <-> position, and h <-> w for the column-major planes).  A workgroup
+// owns a 16 x 16 pixel tile x 32 channels staged in LDS, so that every global access is a run of 16
+// consecutive positions (64 B) of one plane or 32 consecutive channels (128 B) of one pixel.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/sigma_ops.h"
+
+namespace sigma {
+
+namespace {
+
+constexpr int kP = 16;      // pixels per tile side
+constexpr int kC = 32;      // channels per tile
+
+struct MergeArgs {
+    const float* ys;   // (B, 4, d, L)      merge input
+    float* y;          // (B, H, W, d)      merge output
+    const float* dy;   // (B, H, W, d)      split input
+    float* g2;         // (B, 2, d, L)      split output
+    int B, d, H, W;
+};
+
+// LDS tile [c][h][w]: w-rows padded to 17 floats and c-slabs to 273 (both odd), so that walking along w
+// (stride 1), along h (stride 17) and along c (stride 273 = 17 mod 32) all touch distinct banks.
+constexpr int kSlab = kP * (kP + 1) + 1;
+__device__ __forceinline__ int lds_idx(int c, int h, int w) { return c * kSlab + h * (kP + 1) + w; }
+
+__global__ void __launch_bounds__(256) cross_merge_kernel(const MergeArgs a) {
+    __shared__ float t[kC * kSlab];
+    const int H = a.H, W = a.W, d = a.d;
+    const long L = (long)H * W;
+    const int tw = (W + kP - 1) / kP, th = (H + kP - 1) / kP, tc = (d + kC - 1) / kC;
+    int bid = blockIdx.x;
+    const int ci = bid % tc; bid /= tc;
+    const int wi = bid % tw; bid /= tw;
+    const int hi = bid % th; bid /= th;
+    const int b = bid;
+    const int c0 = ci * kC, w0 = wi * kP, h0 = hi * kP;
+    const int tid = threadIdx.x;
+    const float* __restrict__ p0 = a.ys + ((long)(b * 4 + 0) * d) * L;
+    const float* __restrict__ p1 = a.ys + ((long)(b * 4 + 1) * d) * L;
+    const float* __restrict__ p2 = a.ys + ((long)(b * 4 + 2) * d) * L;
+    const float* __restrict__ p3 = a.ys + ((long)(b * 4 + 3) * d) * L;
+    // row-major planes: consecutive threads -> consecutive w
+    for (int e = tid; e < kC * kP * kP; e += 256) {
+        const int wl = e & (kP - 1), hl = (e >> 4) & (kP - 1), cl = e >> 8;
+        const int c = c0 + cl, h = h0 + hl, w = w0 + wl;
+        float v = 0.0f;
+        if (c < d && h < H && w < W) { const long o = (long)c * L + (long)h * W + w; v = p0[o] + p1[o]; }
+        t[lds_idx(cl, hl, wl)] = v;
+    }
+    __syncthreads();
+    // column-major planes: consecutive threads -> consecutive h
+    for (int e = tid; e < kC * kP * kP; e += 256) {
+        const int hl = e & (kP - 1), wl = (e >> 4) & (kP - 1), cl = e >> 8;
+        const int c = c0 + cl, h = h0 + hl, w = w0 + wl;
+        if (c < d && h < H && w < W) { const long o = (long)c * L + (long)w * H + h; t[lds_idx(cl, hl, wl)] += p2[o] + p3[o]; }
+    }
+    __syncthreads();
+    // channels-last output: consecutive threads -> consecutive c
+    float* __restrict__ yb = a.y + (long)b * L * d;
+    for (int e = tid; e < kC * kP * kP; e += 256) {
+        const int cl = e & (kC - 1), wl = (e >> 5) & (kP - 1), hl = e >> 9;
+        const int c = c0 + cl, h = h0 + hl, w = w0 + wl;
+        if (c < d && h < H && w < W) yb[((long)h * W + w) * d + c] = t[lds_idx(cl, hl, wl)];
+    }
+}
+
+__global__ void __launch_bounds__(256) cross_split_kernel(const MergeArgs a) {
+    __shared__ float t[kC * kSlab];
+    const int H = a.H, W = a.W, d = a.d;
+    const long L = (long)H * W;
+    const int tw = (W + kP - 1) / kP, th = (H + kP - 1) / kP, tc = (d + kC - 1) / kC;
+    int bid = blockIdx.x;
+    const int ci = bid % tc; bid /= tc;
+    const int wi = bid % tw; bid /= tw;
+    const int hi = bid % th; bid /= th;
+    const int b = bid;
+    const int c0 = ci * kC, w0 = wi * kP, h0 = hi * kP;
+    const int tid = threadIdx.x;
+    const float* __restrict__ db = a.dy + (long)b * L * d;
+    for (int e = tid; e < kC * kP * kP; e += 256) {
+        const int cl = e & (kC - 1), wl = (e >> 5) & (kP - 1), hl = e >> 9;
+        const int c = c0 + cl, h = h0 + hl, w = w0 + wl;
+        t[lds_idx(cl, hl, wl)] = (c < d && h < H && w < W) ? db[((long)h * W + w) * d + c] : 0.0f;
+    }
+    __syncthreads();
+    float* __restrict__ g_rm = a.g2 + ((long)(b * 2 + 0) * d) * L;
+    float* __restrict__ g_cm = a.g2 + ((long)(b * 2 + 1) * d) * L;
+    for (int e = tid; e < kC * kP * kP; e += 256) {
+        const int wl = e & (kP - 1), hl = (e >> 4) & (kP - 1), cl = e >> 8;
+        const int c = c0 + cl, h = h0 + hl, w = w0 + wl;
+        if (c < d && h < H && w < W) g_rm[(long)c * L + (long)h * W + w] = t[lds_idx(cl, hl, wl)];
+    }
+    for (int e = tid; e < kC * kP * kP; e += 256) {
+        const int hl = e & (kP - 1), wl = (e >> 4) & (kP - 1), cl = e >> 8;
+        const int c = c0 + cl, h = h0 + hl, w = w0 + wl;
+        if (c < d && h < H && w < W) g_cm[(long)c * L + (long)w * H + h] = t[lds_idx(cl, hl, wl)];
+    }
+}
+
+bool grid_for(const sigma_merge_params* p, unsigned* grid) {
+    if (!p || p->batch < 0 || p->channels <= 0 || p->height <= 0 || p->width <= 0) return false;
+    const long n = (long)p->batch * ((p->height + kP - 1) / kP) * ((p->width + kP - 1) / kP) * ((p->channels + kC - 1) / kC);
+    if (n > 2147483647L) return false;
+    *grid = (unsigned)n;
+    return true;
+}
+
+}  // namespace
+
+}  // namespace sigma
+
+extern "C" {
+
+int sigma_cross_merge_nhwc(const sigma_merge_params* p, void* stream) {
+    unsigned grid = 0;
+    if (!sigma::grid_for(p, &grid)) return SIGMA_OPS_ERR_ARG;
+    if (grid == 0) return SIGMA_OPS_OK;
+    if (!p->planes4 || !p->nhwc) return SIGMA_OPS_ERR_ARG;
+    sigma::MergeArgs a{};
+    a.ys = p->planes4; a.y = p->nhwc; a.B = p->batch; a.d = p->channels; a.H = p->height; a.W = p->width;
+    hipLaunchKernelGGL(sigma::cross_merge_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    return hipGetLastError() == hipSuccess ? SIGMA_OPS_OK : SIGMA_OPS_ERR_LAUNCH;
+}
+
+int sigma_cross_split_nhwc(const sigma_merge_params* p, void* stream) {
+    unsigned grid = 0;
+    if (!sigma::grid_for(p, &grid)) return SIGMA_OPS_ERR_ARG;
+    if (grid == 0) return SIGMA_OPS_OK;
+    if (!p->planes2 || !p->nhwc) return SIGMA_OPS_ERR_ARG;
+    sigma::MergeArgs a{};
+    a.dy = p->nhwc; a.g2 = p->planes2; a.B = p->batch; a.d = p->channels; a.H = p->height; a.W = p->width;
+    hipLaunchKernelGGL(sigma::cross_split_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    return hipGetLastError() == hipSuccess ? SIGMA_OPS_OK : SIGMA_OPS_ERR_LAUNCH;
+}
+
+}  // extern "C"

@@ -31,7 +31,7 @@ import torch.nn.functional as F
 import os
 
 from ...selective_scan import selective_scan_fn
-from ...ss2d_fused import dwconv_silu, dwconv_silu_two_orders, ss2d_core, ss2d_core_from_orders
+from ...ss2d_fused import dwconv_silu, dwconv_silu_two_orders, selective_scan_ext, ss2d_core, ss2d_core_from_orders
 
 # SIGMA_SS2D_FUSED=0 selects the plain-autograd formulation of SS2D's core (A/B measurements and
 # the fused-vs-unfused parity test); both run the same HIP scan kernels.
@@ -144,8 +144,8 @@ def ss2d_scan(x: torch.Tensor, x_proj_weight, dt_projs_weight, dt_projs_bias, A_
     """
     B, d, H, W = x.shape
     if _FUSED_SS2D and x.is_cuda:          # CPU tensors take the plain formulation, whose scan raises (no fallback)
-        y = ss2d_core(x, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds)     # (B, d, L)
-        return out_norm(y.transpose(1, 2).reshape(B, H, W, d)).to(x.dtype)
+        y = ss2d_core(x, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds)     # (B, H, W, d)
+        return out_norm(y).to(x.dtype)
     K, c, _ = x_proj_weight.shape                # c = R + 2N
     R = dt_projs_weight.shape[2]
     N = A_logs.shape[1]
@@ -212,7 +212,7 @@ class SS2D(nn.Module):
             xs2 = dwconv_silu_two_orders(xi, self.conv2d.weight, self.conv2d.bias)
             y = ss2d_core_from_orders(xs2, Hq, Wq, self.x_proj_weight, self.dt_projs_weight, self.dt_projs_bias,
                                       self.A_logs, self.Ds)
-            y = self.out_norm(y.transpose(1, 2).reshape(Bq, Hq, Wq, dq)).to(x.dtype)
+            y = self.out_norm(y).to(x.dtype)
         else:
             y = ss2d_scan(self.act(self.conv2d(xi)), self.x_proj_weight, self.dt_projs_weight, self.dt_projs_bias,
                           self.A_logs, self.Ds, self.out_norm)
@@ -440,6 +440,17 @@ class ConMB_SS2D(nn.Module):
         c = R + 2 * N
         seq = torch.cat([c_rgb.flatten(2), c_e.flatten(2)], dim=2)               # (B, d, 2HW): rgb tokens first
         p = torch.matmul(self.x_proj_weight.reshape(2 * c, d), seq)              # both directions in one GEMM
+        if _FUSED_SS2D and seq.is_cuda:
+            # the flipped direction is read backwards by the kernel: no flipped copies of seq / x_dbl / ys
+            p4 = p.view(B, 2, c, L)
+            dts = torch.matmul(self.dt_projs_weight.unsqueeze(0), p4[:, :, :R])  # (B, 2, d, L)
+            ys = selective_scan_ext(seq, dts.reshape(B, 2 * d, L), -torch.exp(self.A_logs.float()), p4[:, :, R:R + N],
+                                    p4[:, :, R + N:], self.Ds.float(), self.dt_projs_bias.float().reshape(-1),
+                                    rev_mask=0b10, u_gshift=1).view(B, 2, d, L)
+            y = ys[:, 0] + ys[:, 1]
+            y_rgb = self.out_norm1(y[..., :HW].transpose(1, 2).reshape(B, H, W, d))
+            y_e = self.out_norm2(y[..., HW:].transpose(1, 2).reshape(B, H, W, d))
+            return y_rgb, y_e
         x_dbl = torch.stack([p[:, :c], p[:, c:].flip(-1)], dim=1)                # (B, 2, c, L)
         dts, Bs, Cs = torch.split(x_dbl, [R, N, N], dim=2)
         dts = torch.matmul(self.dt_projs_weight.unsqueeze(0), dts)               # (B, 2, d, L)

@@ -109,9 +109,80 @@ def dwconv_silu(x, weight, bias):
     return DwConvSiLUTwoOrdersFn.apply(x, weight, bias, 1).view(B, d, H, W)
 
 
+class SelectiveScanExtFn(torch.autograd.Function):
+    """selective scan with the operator extensions of include/sigma_scan.h under autograd:
+    ``rev_mask`` (bit g: group g runs backwards by addressing) and ``u_gshift`` (group g reads the
+    u rows of group g >> u_gshift; u is (B, dim >> u_gshift, L)).  Used by ConMB, whose two
+    directions are the concatenated RGB|X sequence and its flip (vmamba.py:123-163, 369-430)."""
+
+    @staticmethod
+    def forward(ctx, u, delta, A, B, C, D, delta_bias, rev_mask, u_gshift):
+        u, delta = u.float().contiguous(), delta.float().contiguous()
+        B = B.float() if B.stride(-1) == 1 else B.float().contiguous()
+        C = C.float() if C.stride(-1) == 1 else C.float().contiguous()
+        A, D, delta_bias = A.float().contiguous(), D.float().contiguous(), delta_bias.float().contiguous()
+        out, ck = _core.fwd_ext(u, delta, A, B, C, D, delta_bias, True, rev_mask=rev_mask, u_gshift=u_gshift,
+                                need_x=any(ctx.needs_input_grad))
+        ctx.save_for_backward(u, delta, A, B, C, D, delta_bias, ck)
+        ctx.ext = (int(rev_mask), int(u_gshift))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        u, delta, A, B, C, D, delta_bias, ck = ctx.saved_tensors
+        rev_mask, sh = ctx.ext
+        du, ddelta, dA, dB, dC, dD, dbias = _core.bwd_ext(u, delta, A, B, C, D, delta_bias, dout.float().contiguous(), ck,
+                                                          True, rev_mask=rev_mask, u_gshift=sh)
+        if sh:
+            Bsz, dim, L = du.shape
+            G = B.shape[1]
+            rpg = dim // G
+            du = du.view(Bsz, G >> sh, 1 << sh, rpg, L).sum(2).reshape(Bsz, dim >> sh, L)
+        return du, ddelta, dA, dB, dC, dD, dbias, None, None
+
+
+def selective_scan_ext(u, delta, A, B, C, D, delta_bias, rev_mask=0, u_gshift=0):
+    return SelectiveScanExtFn.apply(u, delta, A, B, C, D, delta_bias, rev_mask, u_gshift)
+
+
+def _merge_params(B, d, H, W):
+    from . import _capi
+    p = _capi.MergeParams()
+    p.batch, p.channels, p.height, p.width = B, d, H, W
+    return p
+
+
+def cross_merge_nhwc(ys: torch.Tensor, H: int, W: int) -> torch.Tensor:
+    """(B, 4, d, L) scan planes (group order g = 2*order + flipped, natural positions) -> (B, H, W, d)."""
+    import ctypes
+    from . import _capi
+    B, _, d, L = ys.shape
+    y = torch.empty(B, H, W, d, device=ys.device, dtype=torch.float32)
+    p = _merge_params(B, d, H, W)
+    p.planes4, p.nhwc = ys.data_ptr(), y.data_ptr()
+    with torch.cuda.device(ys.device):
+        _capi.check(_capi.load().sigma_cross_merge_nhwc(ctypes.byref(p), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                    "cross_merge_nhwc")
+    return y
+
+
+def cross_split_nhwc(dy: torch.Tensor) -> torch.Tensor:
+    """(B, H, W, d) -> (B, 2, d, L): the gradient once in row-major and once in column-major order."""
+    import ctypes
+    from . import _capi
+    B, H, W, d = dy.shape
+    g2 = torch.empty(B, 2, d, H * W, device=dy.device, dtype=torch.float32)
+    p = _merge_params(B, d, H, W)
+    p.planes2, p.nhwc = g2.data_ptr(), dy.data_ptr()
+    with torch.cuda.device(dy.device):
+        _capi.check(_capi.load().sigma_cross_split_nhwc(ctypes.byref(p), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                    "cross_split_nhwc")
+    return g2
+
+
 class SS2DCoreFn(torch.autograd.Function):
     """y = CrossMerge(selective_scan(CrossScan(x), ...)); input xs2 = [row-major, column-major]
-    sequences of x, (B, 2, d, H*W) -> y (B, d, H*W)."""
+    sequences of x, (B, 2, d, H*W) -> y channels-last (B, H, W, d), ready for out_norm."""
 
     @staticmethod
     def forward(ctx, xs2, H, W, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds):
@@ -136,10 +207,7 @@ class SS2DCoreFn(torch.autograd.Function):
         need_x = any(ctx.needs_input_grad)
         out, ck = _core.fwd_ext(xs2.view(B, 2 * d, L), delta.view(B, 4 * d, L), A, Bv, Cv, Dp, bias, True,
                                 rev_mask=_REV_MASK, u_gshift=1, need_x=need_x)
-        ys = out.view(B, 4, d, L)
-        y = ys[:, 0] + ys[:, 1]
-        y_cm = ys[:, 2] + ys[:, 3]
-        y += y_cm.view(B, d, W, H).transpose(2, 3).reshape(B, d, L)
+        y = cross_merge_nhwc(out.view(B, 4, d, L), H, W)                       # (B, H, W, d)
         ctx.save_for_backward(xs2, p4, delta, A, Dp, bias, ck, Wst, dtw)
         ctx.dims = (B, d, H, W, c, R, N)
         return y
@@ -150,7 +218,7 @@ class SS2DCoreFn(torch.autograd.Function):
         B, d, H, W, c, R, N = ctx.dims
         L = H * W
         perm = list(_PERM)
-        g2 = _two_orders(dy.float().reshape(B, d, H, W))                       # CrossMerge^T: 2 planes, not 4
+        g2 = cross_split_nhwc(dy.float().contiguous())                         # CrossMerge^T: 2 planes, not 4
         dp4 = torch.empty_like(p4)
         Bv, Cv = p4[:, :, R:R + N], p4[:, :, R + N:]
         du, ddelta, dA, _, _, dD, dbias = _core.bwd_ext(
@@ -191,11 +259,11 @@ class _TwoOrdersFn(torch.autograd.Function):
 
 
 def ss2d_core(x, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds):
-    """x (B, d, H, W) -> (B, d, H*W)"""
+    """x (B, d, H, W) -> (B, H, W, d)"""
     B, d, H, W = x.shape
     return SS2DCoreFn.apply(_TwoOrdersFn.apply(x), H, W, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds)
 
 
 def ss2d_core_from_orders(xs2, H, W, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds):
-    """xs2 (B, 2, d, H*W) as produced by dwconv_silu_two_orders -> (B, d, H*W)"""
+    """xs2 (B, 2, d, H*W) as produced by dwconv_silu_two_orders -> (B, H, W, d)"""
     return SS2DCoreFn.apply(xs2, H, W, x_proj_weight, dt_projs_weight, dt_projs_bias, A_logs, Ds)

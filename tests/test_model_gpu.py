@@ -133,3 +133,46 @@ def test_dwconv_silu_two_orders_matches_torch(shape):
     for n, a, r in zip(["out", "dx", "dw", "db", "out1", "dx1", "dw1", "db1"], res[0], res[1]):
         scale = float(r.abs().max()) + 1e-6
         assert float((a - r).abs().max()) <= 3e-5 * scale + 1e-6 * (H * W * B) ** 0.5, (n, float((a - r).abs().max()), scale)
+
+
+@pytest.mark.parametrize("shape", [(2, 40, 15, 20), (1, 33, 7, 9), (2, 192, 30, 40), (1, 8, 46, 80), (1, 70, 1, 5)])
+def test_cross_merge_and_split_kernels_match_torch(shape):
+    """include/sigma_ops.h merge / split vs the view / transpose formulation (vmamba.py:100-121, 221-224)."""
+    from sigma_amd.ss2d_fused import cross_merge_nhwc, cross_split_nhwc
+    B, d, H, W = shape
+    L = H * W
+    g = torch.Generator().manual_seed(1)
+    ys = torch.randn(B, 4, d, L, generator=g).cuda()
+    ref = (ys[:, 0] + ys[:, 1]).view(B, d, H, W) + (ys[:, 2] + ys[:, 3]).view(B, d, W, H).transpose(2, 3)
+    ref = ref.permute(0, 2, 3, 1).contiguous()
+    torch.testing.assert_close(cross_merge_nhwc(ys, H, W), ref, rtol=0, atol=2e-6)
+    dy = torch.randn(B, H, W, d, generator=g).cuda()
+    g2 = cross_split_nhwc(dy)
+    nchw = dy.permute(0, 3, 1, 2)
+    assert torch.equal(g2[:, 0], nchw.reshape(B, d, L))
+    assert torch.equal(g2[:, 1], nchw.transpose(2, 3).reshape(B, d, L))
+
+
+def test_conmb_scan_by_addressing_equals_flipped_copies():
+    """ConMB's K = 2 scan (vmamba.py:369-430): reversed group by addressing vs materialised flips."""
+    import importlib
+    vm = importlib.import_module("sigma_amd.models.encoders.vmamba")
+    torch.manual_seed(0)
+    blk = vm.ConMB_SS2D(d_model=24, d_state=4).cuda()
+    c_rgb = torch.randn(2, 48, 9, 14, device="cuda")
+    c_e = torch.randn(2, 48, 9, 14, device="cuda")
+    res = {}
+    for fused in (True, False):
+        vm._FUSED_SS2D = fused
+        try:
+            a, b = c_rgb.clone().requires_grad_(), c_e.clone().requires_grad_()
+            blk.zero_grad(set_to_none=True)
+            y1, y2 = blk._scan(a, b)
+            (y1.square().sum() + (y2 * 0.5).sum()).backward()
+            res[fused] = [y1.detach(), y2.detach(), a.grad, b.grad] + [p.grad.clone() for p in
+                         (blk.x_proj_weight, blk.dt_projs_weight, blk.dt_projs_bias, blk.A_logs, blk.Ds)]
+        finally:
+            vm._FUSED_SS2D = True
+    for i, (a, b) in enumerate(zip(res[True], res[False])):
+        scale = float(b.abs().max()) + 1e-6
+        assert float((a - b).abs().max()) <= 3e-4 * scale + 1e-5, (i, float((a - b).abs().max()), scale)
