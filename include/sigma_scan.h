@@ -161,6 +161,8 @@ int sigma_scan_abi_version(void);
  *   "fwd_tiles"                consecutive sequence tiles per workgroup, forward (rows x tiles <= 16)
  *   "fwd_nb" / "bwd_nb"        states per B/C staging block {1,2,4,8}
  *   "no_glds"                  1 = stage B/C through registers instead of global_load_lds
+ *   "bwd_slab2"                1 = two dB/dC slab sets in LDS (one barrier per state) when they fit
+ *   "fwd_prefetch"             2 = no register prefetch of the next tile's u/delta (T = 10)
  * Returns SIGMA_ERR_BAD_OPTION for unknown names / unsupported values. */
 int sigma_scan_set_option(const char *name, int value);
 int sigma_scan_get_option(const char *name);

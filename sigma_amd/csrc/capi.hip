@@ -19,7 +19,7 @@ namespace {
 thread_local std::string g_err;
 
 std::atomic<int> g_opt_fwd_items{0}, g_opt_fwd_waves{0}, g_opt_fwd_tiles{0}, g_opt_fwd_nb{0};
-std::atomic<int> g_opt_bwd_items{0}, g_opt_bwd_waves{0}, g_opt_bwd_nb{0}, g_opt_no_glds{0};
+std::atomic<int> g_opt_bwd_items{0}, g_opt_bwd_waves{0}, g_opt_bwd_nb{0}, g_opt_no_glds{0}, g_opt_bwd_slab2{0}, g_opt_fwd_prefetch{0};
 
 int fail(int code, const char* fmt, ...) {
     char buf[512];
@@ -114,7 +114,7 @@ int pick_items(int L, const int* cand, int ncand, double (*cost)(int), int force
 constexpr int kCUs = 256;
 constexpr size_t kLdsLimit = 160 * 1024;
 
-struct Plan { int items, rows, tiles, nb, grid; bool glds; size_t lds; };
+struct Plan { int items, rows, tiles, nb, grid; bool glds; size_t lds; bool slab2; };
 
 // global_load_lds staging: f32, 16-byte aligned rows, whole chunks in range, 31-bit offsets inside
 // one (batch, group) slice; the per-wave chunk plan holds kStageMaxIt units (scan_device.h).
@@ -137,7 +137,13 @@ Plan plan_fwd(const sigma_scan_fwd_params* p, bool vec) {
     static const int cand[] = {10, 5, 4};
     Plan pl;
     const int forced_items = g_opt_fwd_items.load();
-    pl.items = forced_items == 20 ? 20 : pick_items(p->seqlen, cand, 3, fwd_cost_per_element, forced_items);
+    // measured (tools/bwd_variants.py): with 16 states and long sequences the 1280-element tile wins
+    // (half as many tile starts whose u/delta latency is exposed; 805 vs 961 us at (8,768,19200));
+    // short sequences and few-state scans prefer 640-element tiles with the register prefetch
+    const bool long_rows = (long)p->batch * p->dim >= 12L * kCUs && p->dstate > 8 && p->seqlen >= 10240;
+    pl.items = forced_items == 20 ? 20
+             : (forced_items == 0 && long_rows) ? 20
+             : pick_items(p->seqlen, cand, 3, fwd_cost_per_element, forced_items);
     pl.glds = glds_ok(p, vec);
     const int rpg = p->dim / p->n_groups;
     const long total_rows = (long)p->batch * p->dim;
@@ -145,7 +151,7 @@ Plan plan_fwd(const sigma_scan_fwd_params* p, bool vec) {
     const int ntiles = (p->seqlen + tile - 1) / tile;
     const int fr = g_opt_fwd_waves.load(), fw = g_opt_fwd_tiles.load(), fnb = g_opt_fwd_nb.load();
     double best = 1e300;
-    pl.rows = 1; pl.tiles = 1; pl.nb = 1;
+    pl.rows = 1; pl.tiles = 1; pl.nb = 1; pl.slab2 = false;
     const int maxw = pl.items >= 20 ? 12 : 16;                  // scan_fwd.hip: fwd_max_waves<T>
     for (int R = maxw; R >= 1; --R) {
         if (rpg % R != 0) continue;
@@ -155,6 +161,7 @@ Plan plan_fwd(const sigma_scan_fwd_params* p, bool vec) {
         if (Wmax < 1) Wmax = 1;
         for (int W = Wmax; W >= 1; --W) {
             if (fw > 0 && W != (fw < Wmax ? fw : Wmax)) continue;
+            if (fw == 0 && W > 1 && total_rows / maxw >= kCUs) continue;   // enough rows: never split the sequence
             int NB = W == 1 ? 4 : (W == 2 ? 2 : 1);
             if (fnb > 0) NB = fnb;
             if (NB > p->dstate) NB = p->dstate;
@@ -172,8 +179,9 @@ Plan plan_fwd(const sigma_scan_fwd_params* p, bool vec) {
             if (wgpc > 2) wgpc = 2;
             const long rounds = (nwg + (long)kCUs * wgpc - 1) / ((long)kCUs * wgpc);
             // a CU with few waves runs each of them faster, but not proportionally
-            const double per_step = (0.35 + 0.65 * (double)(waves * wgpc) / 16.0) *
-                                    (1.0 + 2.0 / R + (W > 1 ? 0.15 : 0.0)) * (wgpc >= 2 ? 0.85 : 1.0);
+            // (with <= 8 states the staging share per row matters more than the interleaving: 16 rows win)
+            const double occ = p->dstate > 8 ? (0.35 + 0.65 * (double)(waves * wgpc) / 16.0) : 1.0;
+            const double per_step = occ * (1.0 + 2.0 / R + (W > 1 ? 0.15 : 0.0)) * ((wgpc >= 2 && p->dstate > 8) ? 0.85 : 1.0);
             const double cost = (double)rounds * nsuper * per_step;
             if (cost < best) { best = cost; pl.rows = R; pl.tiles = W; pl.nb = NB; }
         }
@@ -190,6 +198,7 @@ Plan plan_bwd(const sigma_scan_fwd_params* p, bool vec) {
     pl.items = pick_items(p->seqlen, cand, 3, bwd_cost_per_element, g_opt_bwd_items.load());
     pl.glds = glds_ok(p, vec);
     pl.tiles = 1;
+    pl.slab2 = false;
     const int rpg = p->dim / p->n_groups;
     const long total_rows = (long)p->batch * p->dim;
     const int fr = g_opt_bwd_waves.load();
@@ -212,7 +221,8 @@ Plan plan_bwd(const sigma_scan_fwd_params* p, bool vec) {
         if (cost < best) { best = cost; pl.rows = R; }
     }
     pl.grid = (int)(total_rows / pl.rows);
-    pl.lds = sigma::bwd_lds_bytes(pl.items, pl.rows, pl.nb, p->dstate);
+    pl.slab2 = g_opt_bwd_slab2.load() == 1 && sigma::bwd_lds_bytes(pl.items, pl.rows, pl.nb, p->dstate, true) <= kLdsLimit;
+    pl.lds = sigma::bwd_lds_bytes(pl.items, pl.rows, pl.nb, p->dstate, pl.slab2);
     pl.glds = pl.glds && glds_fits(pl.items, pl.nb, 1, pl.rows);
     return pl;
 }
@@ -236,6 +246,8 @@ OptDesc g_opts[] = {
     {"fwd_nb", &g_opt_fwd_nb, {0, 1, 2, 4, 8, -1}},
     {"bwd_nb", &g_opt_bwd_nb, {0, 1, 2, 4, 8, -1}},
     {"no_glds", &g_opt_no_glds, {0, 1, -1}},
+    {"bwd_slab2", &g_opt_bwd_slab2, {0, 1, 2, -1}},        // 1 = two dB/dC slab sets when they fit
+    {"fwd_prefetch", &g_opt_fwd_prefetch, {0, 1, 2, -1}},  // 2 = no register prefetch of the next tile's u/delta (T = 10)
 };
 }  // namespace
 
@@ -286,7 +298,8 @@ int sigma_selective_scan_fwd(const sigma_scan_fwd_params* p, void* stream) {
     const Plan pl = plan_fwd(p, vec);
     if (pl.lds > kLdsLimit) return fail(SIGMA_ERR_BAD_SHAPE, "LDS budget exceeded (%zu B)", pl.lds);
     const sigma::FwdArgs a = make_fwd_args(p, pl.rows, pl.tiles, pl.nb, vec);
-    hipError_t e = sigma::launch_scan_fwd(a, p->io_dtype, pl.items, pl.glds, static_cast<hipStream_t>(stream));
+    hipError_t e = sigma::launch_scan_fwd(a, p->io_dtype, pl.items, pl.glds, g_opt_fwd_prefetch.load() != 2,
+                                          static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(SIGMA_ERR_LAUNCH, "scan_fwd launch failed: %s", hipGetErrorString(e));
     return SIGMA_OK;
 }
@@ -350,6 +363,7 @@ int sigma_selective_scan_bwd(const sigma_scan_bwd_params* q, void* stream) {
     if (q->dout_group_shift < 0 || q->dout_group_shift > 5)
         return fail(SIGMA_ERR_BAD_SHAPE, "dout_group_shift must be in [0, 5] (got %d)", q->dout_group_shift);
     a.P = P;
+    a.slab2 = pl.slab2 ? 1 : 0;
     a.g_gshift = q->dout_group_shift;
     a.out_vec_ok = (aligned_to(q->dB, 16) && aligned_to(q->dC, 16) && q->dB_batch_stride % 4 == 0 &&
                     q->dB_group_stride % 4 == 0 && q->dB_dstate_stride % 4 == 0 && q->dC_batch_stride % 4 == 0 &&

@@ -84,7 +84,7 @@ __device__ __forceinline__ void scan_bwd_body(const BwdArgs& q, float* smem, int
     const int bufsz = 2 * NB * TILE;
     float* sBC = smem;                                // [2][2][NB][TILE]
     float* sRed = sBC + 2 * bufsz;                    // [R][2][TILE] per-row dB/dC terms of one state
-    float* sX0 = sRed + R * 2 * TILE;                 // [R][TPS][N] state at tile start
+    float* sX0 = sRed + (q.slab2 ? 2 : 1) * R * 2 * TILE;   // [R][TPS][N] state at tile start
     float* sRv = sX0 + R * TPS * N;                   // [R][N] reverse carry a*dx of the tile to the right
     float* sdA = sRv + R * N;                         // [R][N]
     float* sA = sdA + R * N;                          // [R][N] A[r, n]
@@ -300,9 +300,10 @@ __device__ __forceinline__ void scan_bwd_body(const BwdArgs& q, float* smem, int
                     // Reverse replay.  The per-row terms of dB[n, l] / dC[n, l] go straight to this
                     // wave's LDS slab (position order), VW at a time, to keep registers free; then
                     // all threads add the R slabs column-wise.
-                    lds_barrier();                               // slab free (previous state reduced)
+                    float* sRedN = sRed + ((q.slab2 && (n & 1)) ? R * 2 * TILE : 0);
+                    if (!q.slab2) lds_barrier();                 // slab free (previous state reduced)
                     {
-                        float* __restrict__ slab = sRed + wave * 2 * TILE + lane * T;
+                        float* __restrict__ slab = sRedN + wave * 2 * TILE + lane * T;
 #pragma unroll
                         for (int qq = T / VW - 1; qq >= 0; --qq) {
                             float bq[VW], vb[VW], vc[VW];
@@ -344,7 +345,7 @@ __device__ __forceinline__ void scan_bwd_body(const BwdArgs& q, float* smem, int
                         const int p4 = REV ? (TILE - 4 - q4) : q4;  // lowest slab position of the 4
                         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
                         for (int w = 0; w < R; ++w) {
-                            const float4 v = *reinterpret_cast<const float4*>(sRed + w * 2 * TILE + c * TILE + p4);
+                            const float4 v = *reinterpret_cast<const float4*>(sRedN + w * 2 * TILE + c * TILE + p4);
                             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
                         }
                         if (REV) { const float4 t = acc; acc = make_float4(t.w, t.z, t.y, t.x); }
@@ -461,7 +462,7 @@ reduce_partials_kernel(const float* __restrict__ wsB, const float* __restrict__ 
 
 template <typename io_t, int T, bool GLDS>
 static hipError_t launch_bwd_t(const BwdArgs& a, hipStream_t stream) {
-    const size_t lds = bwd_lds_bytes(T, a.f.R, a.f.NB, a.f.N);
+    const size_t lds = bwd_lds_bytes(T, a.f.R, a.f.NB, a.f.N, a.slab2 != 0);
     const int grid = a.f.rowblocks * a.f.batch;
     auto kern = scan_bwd_kernel<io_t, T, GLDS>;
     if (lds > 48 * 1024) {

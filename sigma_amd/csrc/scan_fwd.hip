@@ -291,21 +291,21 @@ static hipError_t launch_fwd_t(const FwdArgs& a, hipStream_t stream) {
 }
 
 template <typename io_t, bool GLDS>
-static hipError_t launch_fwd_io(const FwdArgs& a, int T, hipStream_t stream) {
+static hipError_t launch_fwd_io(const FwdArgs& a, int T, bool prefetch, hipStream_t stream) {
     switch (T) {
         case 4: return launch_fwd_t<io_t, 4, GLDS, true>(a, stream);
         case 5: return launch_fwd_t<io_t, 5, GLDS, true>(a, stream);
-        case 10: return launch_fwd_t<io_t, 10, GLDS, false>(a, stream);
+        case 10: return prefetch ? launch_fwd_t<io_t, 10, GLDS, true>(a, stream) : launch_fwd_t<io_t, 10, GLDS, false>(a, stream);
         case 20: return launch_fwd_t<io_t, 20, GLDS, false>(a, stream);
         default: return hipErrorInvalidValue;
     }
 }
 
-hipError_t launch_scan_fwd(const FwdArgs& a, int dtype, int T, bool glds, hipStream_t stream) {
+hipError_t launch_scan_fwd(const FwdArgs& a, int dtype, int T, bool glds, bool prefetch, hipStream_t stream) {
     switch (dtype) {
-        case 0: return glds ? launch_fwd_io<float, true>(a, T, stream) : launch_fwd_io<float, false>(a, T, stream);
-        case 1: return launch_fwd_io<f16_t, false>(a, T, stream);
-        case 2: return launch_fwd_io<bf16_t, false>(a, T, stream);
+        case 0: return glds ? launch_fwd_io<float, true>(a, T, prefetch, stream) : launch_fwd_io<float, false>(a, T, prefetch, stream);
+        case 1: return launch_fwd_io<f16_t, false>(a, T, false, stream);
+        case 2: return launch_fwd_io<bf16_t, false>(a, T, false, stream);
         default: return hipErrorInvalidValue;
     }
 }

@@ -13,13 +13,13 @@ inline size_t fwd_lds_bytes(int T, int R, int W, int NB, int N) {
 
 // backward: double-buffered B/C stage [2][2][NB][TILE] + per-wave dB/dC term slabs [R][2][TILE]
 // + per-wave scratch: tile-start states of one checkpoint span, reverse carry, dA partials, A
-inline size_t bwd_lds_bytes(int T, int R, int NB, int N) {
+inline size_t bwd_lds_bytes(int T, int R, int NB, int N, bool slab2 = false) {
     const size_t tile = (size_t)kWave * T;
     const int tps = kCkptPitch / (kWave * T);
-    return sizeof(float) * (2 * 2 * (size_t)NB * tile + 2 * (size_t)R * tile + (size_t)R * N * (tps + 3));
+    return sizeof(float) * (2 * 2 * (size_t)NB * tile + (slab2 ? 2 : 1) * 2 * (size_t)R * tile + (size_t)R * N * (tps + 3));
 }
 
-hipError_t launch_scan_fwd(const FwdArgs& a, int dtype, int T, bool glds, hipStream_t stream);
+hipError_t launch_scan_fwd(const FwdArgs& a, int dtype, int T, bool glds, bool prefetch, hipStream_t stream);
 hipError_t launch_scan_bwd(const BwdArgs& a, int dtype, int T, bool glds, hipStream_t stream);
 hipError_t launch_selftest(float* out, hipStream_t stream);
 

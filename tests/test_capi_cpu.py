@@ -91,10 +91,18 @@ def test_options_and_launch_plan():
     assert items in (4, 5, 10, 20) and 1 <= rows <= 16 and 1 <= rows * tiles <= 16 and nb in (1, 2, 4, 8)
     assert (768 // 4) % rows == 0 and grid == 768 // rows and lds <= 160 * 1024
     assert tiles > 1 and grid >= 128          # one image per GPU still fills the chip
-    # a training batch has enough rows: 8 rows x 1 tile per workgroup, two workgroups per CU
+    # a training batch has enough rows: no sequence split; long 16-state rows take 1280-element tiles ...
     pb = _params(batch=16, dim=768, seqlen=19200, dstate=16, n_groups=4, n_chunks=10)
     assert lib.sigma_scan_fwd_plan(ctypes.byref(pb), ctypes.byref(plan)) == 0
-    assert plan[1] == 8 and plan[4] == 1 and plan[2] == 16 * 768 // 8 and 2 * plan[3] <= 160 * 1024
+    assert plan[0] == 20 and plan[1] == 12 and plan[4] == 1 and plan[2] == 16 * 768 // 12
+    # ... short ones 640-element tiles, 8 rows per workgroup, two workgroups per CU
+    pc = _params(batch=16, dim=3072, seqlen=1200, dstate=16, n_groups=4, n_chunks=1)
+    assert lib.sigma_scan_fwd_plan(ctypes.byref(pc), ctypes.byref(plan)) == 0
+    assert plan[0] == 10 and plan[1] == 8 and plan[4] == 1 and 2 * plan[3] <= 160 * 1024
+    # few-state scans (fusion / decoder): 16 rows share one B/C stage
+    pd = _params(batch=8, dim=768, seqlen=19200, dstate=4, n_groups=4, n_chunks=10)
+    assert lib.sigma_scan_fwd_plan(ctypes.byref(pd), ctypes.byref(plan)) == 0
+    assert plan[0] == 10 and plan[1] == 16 and plan[4] == 1
     _capi.set_option("fwd_waves", 16)
     try:
         assert lib.sigma_scan_fwd_plan(ctypes.byref(p), ctypes.byref(plan)) == 0

@@ -311,7 +311,7 @@ def test_strided_and_unaligned_inputs():
                                  ("fwd_waves", 1), ("fwd_waves", 2), ("fwd_waves", 16), ("fwd_tiles", 1),
                                  ("fwd_tiles", 2), ("fwd_tiles", 4), ("fwd_nb", 1), ("fwd_nb", 2), ("no_glds", 1),
                                  ("bwd_items", 4), ("bwd_items", 5), ("bwd_items", 10), ("bwd_waves", 1),
-                                 ("bwd_waves", 8), ("bwd_nb", 1), ("bwd_nb", 2)])
+                                 ("bwd_waves", 8), ("bwd_nb", 1), ("bwd_nb", 2), ("bwd_slab2", 1)])
 def test_every_launch_geometry_is_correct(opt):
     """All (items per lane, rows per workgroup) variants compute the same thing."""
     from sigma_amd import _capi
