@@ -85,6 +85,23 @@ class KernelTimer:
         return agg
 
 
+def measured_traffic(kind, shape):
+    """HBM bytes per launch of a scan kernel from the committed PMC measurement
+    (profiles/scan_traffic.json, produced by tools/gpu_pmc.sh + tools/pmc_traffic.py with the
+    guide's gfx950 correction: FETCH_SIZE doubled for wide coalesced reads).  None if that shape
+    was not measured -- bench.py itself cannot collect PMC counters."""
+    path = os.path.join(ROOT, "profiles", "scan_traffic.json")
+    try:
+        with open(path) as f:
+            table = json.load(f)
+    except OSError:
+        return None
+    for e in table.get("entries", []):
+        if e["kernel"] == f"scan_{kind}" and list(e["shape"]) == list(shape):
+            return e["hbm_bytes_per_launch"]
+    return None
+
+
 def scan_bytes(kind, key):
     B, KD, L, N, G, es = key
     if kind == "fwd":       # SURVEY.md 8(d), training: + checkpoint write
@@ -202,7 +219,8 @@ def main():
         if rows:
             d = rows[0]
             roof = dict(bound="hbm", achieved=round(d["GBs"], 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=round(d["GBs"] / HBM_PEAK_GBS, 4), traffic=None, kernel=d["kernel"], shape=d["shape"],
+                        frac=round(d["GBs"] / HBM_PEAK_GBS, 4), traffic=measured_traffic(d["kernel"][5:], d["shape"]),
+                        algorithmic_bytes=int(d["algorithmic_MB"] * 1e6), kernel=d["kernel"], shape=d["shape"],
                         avg_launch_us=round(d["avg_us"], 1), launches=d["launches"],
                         share_of_scan_time=round(d["total_ms"] / scan_ms, 3),
                         scan_share_of_step=round(scan_ms / (elapsed * 1e3), 3))
@@ -211,7 +229,8 @@ def main():
         if fwd_rows:
             d = fwd_rows[0]
             roof_fwd = dict(bound="hbm", achieved=round(d["GBs"], 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                            frac=round(d["GBs"] / HBM_PEAK_GBS, 4), kernel=d["kernel"], shape=d["shape"],
+                            frac=round(d["GBs"] / HBM_PEAK_GBS, 4), traffic=measured_traffic("fwd", d["shape"]),
+                            algorithmic_bytes=int(d["algorithmic_MB"] * 1e6), kernel=d["kernel"], shape=d["shape"],
                             avg_launch_us=round(d["avg_us"], 1), launches=d["launches"])
         if a.kernel_report:
             os.makedirs(os.path.dirname(os.path.abspath(a.kernel_report)) or ".", exist_ok=True)

@@ -71,6 +71,33 @@ typedef struct sigma_merge_params {
 int sigma_cross_merge_nhwc(const sigma_merge_params *params, void *stream);
 int sigma_cross_split_nhwc(const sigma_merge_params *params, void *stream);
 
+/*   sigma_layernorm_fwd / sigma_layernorm_bwd
+ *       nn.LayerNorm(C, eps=1e-5, affine) over the last dimension of a contiguous (rows, C) fp32
+ *       tensor: every LayerNorm of the hot path (vmamba.py:617, 717, 1196-1197, 1448-1449, 1693,
+ *       1783, 1797; MambaDecoder.py:18, 41, 93).  C % 4 == 0, C <= 2048.
+ *       bwd: dx fully written; dgamma / dbeta fully written (deterministic two-stage column sums
+ *       through `workspace` of sigma_layernorm_bwd_partial_rows(rows) * 2 * C floats).            */
+typedef struct sigma_layernorm_params {
+    int64_t rows;
+    int32_t channels;
+    float eps;
+    const float *x;        /* (rows, C)                       */
+    const float *gamma;    /* (C)                             */
+    const float *beta;     /* (C) or NULL                     */
+    float *y;              /* fwd out (rows, C)               */
+    float *mean;           /* fwd out / bwd in (rows), or NULL in a forward that needs no backward */
+    float *rstd;           /* fwd out / bwd in (rows)         */
+    const float *dy;       /* bwd in  (rows, C)               */
+    float *dx;             /* bwd out (rows, C)               */
+    float *dgamma;         /* bwd out (C)                     */
+    float *dbeta;          /* bwd out (C) or NULL             */
+    float *workspace;      /* bwd scratch                     */
+} sigma_layernorm_params;
+
+int sigma_layernorm_fwd(const sigma_layernorm_params *params, void *stream);
+int sigma_layernorm_bwd(const sigma_layernorm_params *params, void *stream);
+int sigma_layernorm_bwd_partial_rows(int64_t rows);
+
 #ifdef __cplusplus
 }
 #endif

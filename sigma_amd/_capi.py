@@ -82,8 +82,20 @@ class MergeParams(ctypes.Structure):
     ]
 
 
+class LayerNormParams(ctypes.Structure):
+    """mirror of sigma_layernorm_params (include/sigma_ops.h)"""
+    _fields_ = [
+        ("rows", ctypes.c_int64), ("channels", ctypes.c_int32), ("eps", ctypes.c_float),
+        ("x", ctypes.c_void_p), ("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p),
+        ("y", ctypes.c_void_p), ("mean", ctypes.c_void_p), ("rstd", ctypes.c_void_p),
+        ("dy", ctypes.c_void_p), ("dx", ctypes.c_void_p), ("dgamma", ctypes.c_void_p), ("dbeta", ctypes.c_void_p),
+        ("workspace", ctypes.c_void_p),
+    ]
+
+
 # every symbol include/sigma_ops.h declares
-OPS_SYMBOLS = ("sigma_dwconv3x3_silu_fwd", "sigma_dwconv3x3_silu_bwd", "sigma_cross_merge_nhwc", "sigma_cross_split_nhwc")
+OPS_SYMBOLS = ("sigma_dwconv3x3_silu_fwd", "sigma_dwconv3x3_silu_bwd", "sigma_cross_merge_nhwc", "sigma_cross_split_nhwc",
+               "sigma_layernorm_fwd", "sigma_layernorm_bwd", "sigma_layernorm_bwd_partial_rows")
 
 # every symbol include/sigma_scan.h declares; tests check the library exports all of them
 EXPORTED_SYMBOLS = (
@@ -138,7 +150,11 @@ def load() -> ctypes.CDLL:
     lib.sigma_scan_selftest.restype = ctypes.c_int
     for name in OPS_SYMBOLS:
         fn = getattr(lib, name)
-        fn.argtypes = [P(MergeParams if "cross_" in name else DwConvParams), ctypes.c_void_p]
+        if name == "sigma_layernorm_bwd_partial_rows":
+            fn.argtypes = [ctypes.c_int64]
+        else:
+            st = MergeParams if "cross_" in name else LayerNormParams if "layernorm" in name else DwConvParams
+            fn.argtypes = [P(st), ctypes.c_void_p]
         fn.restype = ctypes.c_int
     if lib.sigma_scan_abi_version() != SIGMA_SCAN_ABI_VERSION:
         raise SigmaHipUnavailable(

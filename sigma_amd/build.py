@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "lib", "obj")
 LIB = os.path.join(HERE, "lib", "libsigma_hip.so")
-SOURCES = ["scan_fwd.hip", "scan_bwd.hip", "selftest.hip", "capi.hip", "dwconv.hip", "merge.hip"]
+SOURCES = ["scan_fwd.hip", "scan_bwd.hip", "selftest.hip", "capi.hip", "dwconv.hip", "merge.hip", "layernorm.hip"]
 HEADERS = ["scan_device.h", "scan_launch.h", os.path.join("..", "..", "include", "sigma_scan.h"),
            os.path.join("..", "..", "include", "sigma_ops.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -46,23 +46,36 @@ def _compile(src: str, force: bool, extra) -> str:
     return obj
 
 
-def build(force: bool = False, verbose: bool = False, extra=()) -> str:
-    os.makedirs(OBJ, exist_ok=True)
-    with cf.ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
-        objs = list(ex.map(lambda s: _compile(s, force, list(extra)), SOURCES))
-    if force or _newer(LIB, objs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
-        subprocess.check_call(cmd)
+def build(force: bool = False, verbose: bool = False, extra=(), variant: str = "") -> str:
+    """variant: experimental build of the same ABI into lib/libsigma_hip_<variant>.so (select it with
+    SIGMA_HIP_LIB=...); `extra` flags apply to every translation unit."""
+    global OBJ
+    lib = LIB if not variant else LIB.replace(".so", f"_{variant}.so")
+    obj_saved = OBJ
+    if variant:
+        OBJ = os.path.join(HERE, "lib", f"obj_{variant}")
+    try:
+        os.makedirs(OBJ, exist_ok=True)
+        with cf.ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+            objs = list(ex.map(lambda s: _compile(s, force, list(extra)), SOURCES))
+        if force or _newer(lib, objs):
+            cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs]
+            subprocess.check_call(cmd)
+    finally:
+        OBJ = obj_saved
     if verbose:
-        print(f"built {LIB} ({os.path.getsize(LIB) / 1024:.0f} KiB)")
-    return LIB
+        print(f"built {lib} ({os.path.getsize(lib) / 1024:.0f} KiB)")
+    return lib
 
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--force", action="store_true")
     ap.add_argument("--resource-usage", action="store_true", help="print per-kernel VGPR/LDS usage")
+    ap.add_argument("--variant", default="", help="build lib/libsigma_hip_<variant>.so with --flags")
+    ap.add_argument("--flags", default="", help="extra hipcc flags (space separated) for a variant build")
     a = ap.parse_args()
     extra = ["-Rpass-analysis=kernel-resource-usage"] if a.resource_usage else []
-    build(force=a.force or a.resource_usage, verbose=True, extra=extra)
+    extra += a.flags.split()
+    build(force=a.force or a.resource_usage, verbose=True, extra=extra, variant=a.variant)
     sys.exit(0)

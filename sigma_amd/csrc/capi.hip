@@ -206,7 +206,7 @@ Plan plan_bwd(const sigma_scan_fwd_params* p, bool vec) {
     if (NB > p->dstate) NB = p->dstate;
     double best = 1e300;
     pl.rows = 1; pl.nb = NB;
-    const int maxw = pl.items >= 10 ? 12 : 16;                        // scan_bwd.hip: bwd_max_waves<T>
+    const int maxw = pl.items >= 10 ? sigma::kBwdMaxWavesT10 : 16;   // scan_bwd.hip: bwd_max_waves<T>
     for (int R = maxw; R >= 1; --R) {
         if (rpg % R != 0) continue;
         if (fr > 0 && R != fr && rpg % fr == 0 && fr <= maxw) continue;   // forced rows (when legal)

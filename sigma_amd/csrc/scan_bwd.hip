@@ -406,7 +406,7 @@ __device__ __forceinline__ void scan_bwd_body(const BwdArgs& q, float* smem, int
 
 // T = 10 keeps ~90 values per lane live (5 per-element accumulators + a, x, g*C per state): it
 // needs ~150 VGPRs, i.e. 3 waves per SIMD = 12 rows per workgroup; T = 4 / 5 fit 16.
-template <int T> struct bwd_max_waves { static constexpr int value = (T >= 10) ? 12 : 16; };
+template <int T> struct bwd_max_waves { static constexpr int value = (T >= 10) ? kBwdMaxWavesT10 : 16; };
 
 template <typename io_t, int T, bool GLDS>
 __global__ void __launch_bounds__(64 * bwd_max_waves<T>::value)

@@ -3,7 +3,15 @@
 #include <hip/hip_runtime.h>
 #include "scan_device.h"
 
+// rows (waves) per workgroup the backward kernel may use with T = 10 (640-element tiles):
+// 12 = ~164 VGPRs, 3 waves per SIMD; 16 needs the kernel to fit 128 VGPRs (build knob for A/B runs)
+#ifndef SIGMA_BWD_MAXW_T10
+#define SIGMA_BWD_MAXW_T10 12
+#endif
+
 namespace sigma {
+
+constexpr int kBwdMaxWavesT10 = SIGMA_BWD_MAXW_T10;
 
 // forward: double-buffered B/C stage [2][2][NB][W][TILE] + tile aggregates + A, running state
 inline size_t fwd_lds_bytes(int T, int R, int W, int NB, int N) {

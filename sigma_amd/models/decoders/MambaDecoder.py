@@ -8,6 +8,8 @@ from __future__ import annotations
 
 import torch
 import torch.nn as nn
+
+from ...layernorm import LayerNorm
 import torch.nn.functional as F
 
 from ..encoders.vmamba import CVSSDecoderBlock
@@ -22,7 +24,7 @@ def _up2(x_nhwc: torch.Tensor) -> torch.Tensor:
 class PatchExpand(nn.Module):
     """Linear(C -> 2C), pixel-shuffle 2x2 ('b h w (p1 p2 c) -> b (h p1) (w p2) c'), LayerNorm(C/2)."""
 
-    def __init__(self, input_resolution, dim, dim_scale=2, norm_layer=nn.LayerNorm):
+    def __init__(self, input_resolution, dim, dim_scale=2, norm_layer=LayerNorm):
         super().__init__()
         self.input_resolution = input_resolution
         self.dim = dim
@@ -39,7 +41,7 @@ class PatchExpand(nn.Module):
 class UpsampleExpand(nn.Module):
     """Linear(C -> C/2), bilinear x2, LayerNorm(C/2)."""
 
-    def __init__(self, input_resolution, dim, patch_size=4, norm_layer=nn.LayerNorm):
+    def __init__(self, input_resolution, dim, patch_size=4, norm_layer=LayerNorm):
         super().__init__()
         self.input_resolution = input_resolution
         self.dim = dim
@@ -55,7 +57,7 @@ class UpsampleExpand(nn.Module):
 class FinalUpsample_X4(nn.Module):
     """Linear, bilinear x2, Linear, bilinear x2, LayerNorm -- back to the input resolution."""
 
-    def __init__(self, input_resolution, dim, patch_size=4, norm_layer=nn.LayerNorm):
+    def __init__(self, input_resolution, dim, patch_size=4, norm_layer=LayerNorm):
         super().__init__()
         self.input_resolution = input_resolution
         self.dim = dim
@@ -75,7 +77,7 @@ class Mamba_up(nn.Module):
     """`depth` CVSS blocks (d_state 4) followed by an optional UpsampleExpand."""
 
     def __init__(self, dim, input_resolution, depth, dt_rank="auto", d_state=4, ssm_ratio=2.0, attn_drop_rate=0.0,
-                 drop_rate=0.0, mlp_ratio=4.0, drop_path=0.1, norm_layer=nn.LayerNorm, upsample=None,
+                 drop_rate=0.0, mlp_ratio=4.0, drop_path=0.1, norm_layer=LayerNorm, upsample=None,
                  use_checkpoint=False, **kwargs):
         super().__init__()
         self.input_resolution = input_resolution
@@ -96,7 +98,7 @@ class Mamba_up(nn.Module):
 class MambaDecoder(nn.Module):
     def __init__(self, img_size=(480, 640), in_channels=(96, 192, 384, 768), num_classes=40, dropout_ratio=0.1,
                  embed_dim=96, align_corners=False, patch_size=4, depths=(4, 4, 4, 4), mlp_ratio=4.0, drop_rate=0.0,
-                 attn_drop_rate=0.0, drop_path_rate=0.1, norm_layer=nn.LayerNorm, use_checkpoint=False,
+                 attn_drop_rate=0.0, drop_path_rate=0.1, norm_layer=LayerNorm, use_checkpoint=False,
                  deep_supervision=False, **kwargs):
         super().__init__()
         if deep_supervision:

@@ -12,11 +12,13 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
+from ...layernorm import LayerNorm
+
 from .vmamba import Backbone_VSSM, ConcatMambaFusionBlock, CrossMambaFusionBlock
 
 
 class RGBXTransformer(nn.Module):
-    def __init__(self, num_classes=1000, norm_layer=nn.LayerNorm, depths=(2, 2, 27, 2), dims=96, pretrained=None,
+    def __init__(self, num_classes=1000, norm_layer=LayerNorm, depths=(2, 2, 27, 2), dims=96, pretrained=None,
                  mlp_ratio=4.0, downsample_version="v1", ape=False, img_size=(480, 640), patch_size=4,
                  drop_path_rate=0.2, **kwargs):
         super().__init__()

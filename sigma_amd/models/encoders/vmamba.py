@@ -26,6 +26,8 @@ from typing import Optional
 
 import torch
 import torch.nn as nn
+
+from ...layernorm import LayerNorm
 import torch.nn.functional as F
 
 import os
@@ -198,7 +200,7 @@ class SS2D(nn.Module):
         _stacked_ssm_params(self, self.K, self.d_inner, self.d_state, self.dt_rank,
                             dict(dt_scale=dt_scale, dt_init=dt_init, dt_min=dt_min, dt_max=dt_max,
                                  dt_init_floor=dt_init_floor))
-        self.out_norm = nn.LayerNorm(self.d_inner)
+        self.out_norm = LayerNorm(self.d_inner)
         self.out_proj = nn.Linear(self.d_inner, d_model, bias=bias)
         self.dropout = nn.Dropout(dropout) if dropout > 0.0 else nn.Identity()
 
@@ -223,7 +225,7 @@ class SS2D(nn.Module):
 class PatchMerging2D(nn.Module):
     """2x2 patch merging, 'v1' downsample (vmamba.py:612-636): pad odd sizes, gather, LN(4C), Linear(4C->2C)."""
 
-    def __init__(self, dim, out_dim=-1, norm_layer=nn.LayerNorm):
+    def __init__(self, dim, out_dim=-1, norm_layer=LayerNorm):
         super().__init__()
         self.dim = dim
         self.reduction = nn.Linear(4 * dim, (2 * dim) if out_dim < 0 else out_dim, bias=False)
@@ -240,7 +242,7 @@ class PatchMerging2D(nn.Module):
 class VSSBlock(nn.Module):
     """x + DropPath(SS2D(LN(x))) -- Sigma uses mlp_ratio = 0 so there is no FFN branch (vmamba.py:1673-1722)."""
 
-    def __init__(self, hidden_dim=0, drop_path=0.0, norm_layer=nn.LayerNorm, attn_drop_rate=0.0, d_state=16,
+    def __init__(self, hidden_dim=0, drop_path=0.0, norm_layer=LayerNorm, attn_drop_rate=0.0, d_state=16,
                  dt_rank="auto", ssm_ratio=2.0, mlp_ratio=0.0, **kwargs):
         super().__init__()
         if mlp_ratio and mlp_ratio > 0:
@@ -296,7 +298,7 @@ class ChannelAttentionBlock(nn.Module):
 class CVSSDecoderBlock(nn.Module):
     """Channel-aware VSS block of the decoder (vmamba.py:1760-1811)."""
 
-    def __init__(self, hidden_dim=0, drop_path=0.0, norm_layer=nn.LayerNorm, attn_drop_rate=0.0, d_state=16,
+    def __init__(self, hidden_dim=0, drop_path=0.0, norm_layer=LayerNorm, attn_drop_rate=0.0, d_state=16,
                  dt_rank="auto", ssm_ratio=2.0, **kwargs):
         super().__init__()
         self.norm1 = norm_layer(hidden_dim)
@@ -333,8 +335,8 @@ class Cross_Mamba_Attention_SSM(nn.Module):
         self.A_log_2 = _a_log(self.d_state, self.d_inner)
         self.D_1 = _d_skip(self.d_inner)
         self.D_2 = _d_skip(self.d_inner)
-        self.out_norm_1 = nn.LayerNorm(self.d_inner)
-        self.out_norm_2 = nn.LayerNorm(self.d_inner)
+        self.out_norm_1 = LayerNorm(self.d_inner)
+        self.out_norm_2 = LayerNorm(self.d_inner)
 
     def _project(self, x_seq, x_proj, dt_proj):
         """x_seq (B, d, L) -> delta (B, d, L), B (B, N, L), C (B, N, L); bias enters via delta_bias."""
@@ -419,8 +421,8 @@ class ConMB_SS2D(nn.Module):
         _stacked_ssm_params(self, self.K, self.d_inner, self.d_state, self.dt_rank,
                             dict(dt_scale=dt_scale, dt_init=dt_init, dt_min=dt_min, dt_max=dt_max,
                                  dt_init_floor=dt_init_floor))
-        self.out_norm1 = nn.LayerNorm(self.d_inner)
-        self.out_norm2 = nn.LayerNorm(self.d_inner)
+        self.out_norm1 = LayerNorm(self.d_inner)
+        self.out_norm2 = LayerNorm(self.d_inner)
         self.out_proj = nn.Linear(2 * self.d_inner, d_model, bias=bias)
         self.dropout = nn.Dropout(dropout) if dropout > 0.0 else nn.Identity()
         self.avg_pool = nn.AdaptiveAvgPool2d(1)
@@ -498,7 +500,7 @@ class Backbone_VSSM(nn.Module):
 
     def __init__(self, patch_size=4, in_chans=3, num_classes=1000, depths=(2, 2, 9, 2), dims=(96, 192, 384, 768),
                  d_state=16, dt_rank="auto", ssm_ratio=2.0, attn_drop_rate=0.0, drop_rate=0.0, drop_path_rate=0.1,
-                 mlp_ratio=0.0, patch_norm=True, norm_layer=nn.LayerNorm, downsample_version="v1",
+                 mlp_ratio=0.0, patch_norm=True, norm_layer=LayerNorm, downsample_version="v1",
                  use_checkpoint=False, out_indices=(0, 1, 2, 3), pretrained=None, **kwargs):
         super().__init__()
         if downsample_version != "v1":

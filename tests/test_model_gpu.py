@@ -176,3 +176,38 @@ def test_conmb_scan_by_addressing_equals_flipped_copies():
     for i, (a, b) in enumerate(zip(res[True], res[False])):
         scale = float(b.abs().max()) + 1e-6
         assert float((a - b).abs().max()) <= 3e-4 * scale + 1e-5, (i, float((a - b).abs().max()), scale)
+
+
+@pytest.mark.parametrize("shape", [(3, 7, 96), (2, 30, 40, 384), (1, 1200, 768), (5, 1536), (4, 9, 100), (2, 3, 2048),
+                                   (1, 19200, 192)])
+def test_layernorm_hip_matches_aten(shape):
+    """sigma_amd.layernorm.LayerNorm (include/sigma_ops.h) vs F.layer_norm: y, dx, dgamma, dbeta."""
+    import torch.nn.functional as F
+    from sigma_amd.layernorm import LayerNorm
+    C = shape[-1]
+    g = torch.Generator().manual_seed(2)
+    ln = LayerNorm(C).cuda()
+    with torch.no_grad():
+        ln.weight.copy_(1.0 + 0.3 * torch.randn(C, generator=g))
+        ln.bias.copy_(0.2 * torch.randn(C, generator=g))
+    x = (2.0 * torch.randn(*shape, generator=g) + 0.5).cuda()
+    dy = torch.randn(*shape, generator=g).cuda()
+    xa = x.clone().requires_grad_()
+    ya = ln(xa)
+    ya.backward(dy)
+    ga, ba = ln.weight.grad.clone(), ln.bias.grad.clone()
+    ln.zero_grad(set_to_none=True)
+    xr = x.clone().requires_grad_()
+    yr = F.layer_norm(xr, (C,), ln.weight, ln.bias, ln.eps)
+    yr.backward(dy)
+    rows = x.numel() // C
+    torch.testing.assert_close(ya, yr, rtol=1e-5, atol=2e-5)
+    torch.testing.assert_close(xa.grad, xr.grad, rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(ga, ln.weight.grad, rtol=1e-4, atol=2e-5 * rows ** 0.5)
+    torch.testing.assert_close(ba, ln.bias.grad, rtol=1e-4, atol=2e-5 * rows ** 0.5)
+    # forward-only (no mean / rstd buffers) and a non-contiguous input
+    with torch.no_grad():
+        torch.testing.assert_close(ln(x), yr.detach(), rtol=1e-5, atol=2e-5)
+        if x.dim() == 3:
+            xt = x.transpose(0, 1)
+            torch.testing.assert_close(ln(xt), F.layer_norm(xt, (C,), ln.weight, ln.bias, ln.eps), rtol=1e-5, atol=2e-5)

@@ -9,9 +9,8 @@ from tools.scan_bench import SHAPES, make, time_call, bwd_bytes, fwd_bytes
 
 VARIANTS = [dict(), dict(bwd_nb=2), dict(bwd_nb=2, bwd_slab2=1), dict(bwd_waves=6), dict(bwd_waves=6, bwd_nb=2),
             dict(bwd_waves=8, bwd_nb=2, bwd_slab2=1), dict(bwd_items=5), dict(bwd_items=5, bwd_slab2=1)]
-FV = [dict(), dict(fwd_prefetch=1), dict(fwd_prefetch=1, fwd_waves=4), dict(fwd_prefetch=1, fwd_waves=16), dict(fwd_items=20),
-      dict(fwd_items=20, fwd_waves=6), dict(fwd_items=20, fwd_waves=4), dict(fwd_waves=4), dict(fwd_waves=2), dict(fwd_items=5, fwd_waves=4)]
-VARIANTS = []
+FV = [dict()]
+VARIANTS = [dict(), dict(bwd_waves=12), dict(bwd_waves=8)]
 for name in sys.argv[1:] or ["enc_s2_b16", "enc_s0_b8", "dec_s0_b8"]:
     shape = SHAPES[name]
     u, delta, A, Bm, Cm, D, bias, dout = make(shape)
