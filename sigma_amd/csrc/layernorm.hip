@@ -150,15 +150,37 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const LnArgs a) {
 }
 
 // dgamma[c] = sum_w ws[w][0][c], dbeta[c] = sum_w ws[w][1][c]   (fixed order)
+// 16 columns x 16 row groups per workgroup: a thread adds every 16th partial row with four independent
+// accumulators (the loads of 4 x 16 rows are in flight together), then the 16 groups meet in LDS.
 __global__ void __launch_bounds__(256) ln_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dgamma,
                                                         float* __restrict__ dbeta, int nwaves, int C) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;     // over 2*C
-    if (i >= 2 * C) return;
-    const int which = i / C, c = i - which * C;
-    float acc = 0.0f;
-    for (int w = 0; w < nwaves; ++w) acc += ws[((long)w * 2 + which) * C + c];
-    if (which == 0) dgamma[c] = acc;
-    else if (dbeta) dbeta[c] = acc;
+    __shared__ float red[16][17];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + tx;                       // over 2*C
+    const bool live = i < 2 * C;
+    const int which = live ? i / C : 0, c = live ? i - which * C : 0;
+    const float* __restrict__ col = ws + (long)which * C + c;
+    const long stride = 2L * C;
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    if (live) {
+        int w = ty;
+        for (; w + 48 < nwaves; w += 64) {
+            a0 += col[(long)w * stride];
+            a1 += col[(long)(w + 16) * stride];
+            a2 += col[(long)(w + 32) * stride];
+            a3 += col[(long)(w + 48) * stride];
+        }
+        for (; w < nwaves; w += 16) a0 += col[(long)w * stride];
+    }
+    red[ty][tx] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (ty == 0 && live) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc += red[k][tx];
+        if (which == 0) dgamma[c] = acc;
+        else if (dbeta) dbeta[c] = acc;
+    }
 }
 
 template <typename F>
@@ -228,7 +250,7 @@ int sigma_layernorm_bwd(const sigma_layernorm_params* p, void* stream) {
         if (hipGetLastError() != hipSuccess) return SIGMA_OPS_ERR_LAUNCH;
     }
     const int nw = p->rows > 0 ? grid * 4 : 0;
-    hipLaunchKernelGGL(sigma::ln_reduce_kernel, dim3((2 * p->channels + 255) / 256), dim3(256), 0, s, p->workspace, p->dgamma,
+    hipLaunchKernelGGL(sigma::ln_reduce_kernel, dim3((2 * p->channels + 15) / 16), dim3(256), 0, s, p->workspace, p->dgamma,
                        p->dbeta, nw, p->channels);
     return hipGetLastError() == hipSuccess ? SIGMA_OPS_OK : SIGMA_OPS_ERR_LAUNCH;
 }
