@@ -76,7 +76,8 @@ int sigma_cross_split_nhwc(const sigma_merge_params *params, void *stream);
  *       tensor: every LayerNorm of the hot path (vmamba.py:617, 717, 1196-1197, 1448-1449, 1693,
  *       1783, 1797; MambaDecoder.py:18, 41, 93).  C % 4 == 0, C <= 2048.
  *       bwd: dx fully written; dgamma / dbeta fully written (deterministic two-stage column sums
- *       through `workspace` of sigma_layernorm_bwd_partial_rows(rows) * 2 * C floats).            */
+ *       through `workspace` of sigma_layernorm_bwd_partial_rows(rows) * 2 * C floats).
+ *       bwd with a gate needs beta as well (the normalised value is recomputed).                  */
 typedef struct sigma_layernorm_params {
     int64_t rows;
     int32_t channels;
@@ -92,6 +93,12 @@ typedef struct sigma_layernorm_params {
     float *dgamma;         /* bwd out (C)                     */
     float *dbeta;          /* bwd out (C) or NULL             */
     float *workspace;      /* bwd scratch                     */
+    /* optional fused gate of SS2D.forward (vmamba.py:1086: y = out_norm(y) * act(z)):
+     * y = LayerNorm(x) * silu(gate);  gate rows are gate_row_stride floats apart (z is the second
+     * half of the in_proj output), dgate is contiguous (rows, C).  NULL gate = plain LayerNorm.  */
+    const float *gate;
+    int64_t gate_row_stride;
+    float *dgate;
 } sigma_layernorm_params;
 
 int sigma_layernorm_fwd(const sigma_layernorm_params *params, void *stream);

@@ -90,6 +90,7 @@ class LayerNormParams(ctypes.Structure):
         ("y", ctypes.c_void_p), ("mean", ctypes.c_void_p), ("rstd", ctypes.c_void_p),
         ("dy", ctypes.c_void_p), ("dx", ctypes.c_void_p), ("dgamma", ctypes.c_void_p), ("dbeta", ctypes.c_void_p),
         ("workspace", ctypes.c_void_p),
+        ("gate", ctypes.c_void_p), ("gate_row_stride", ctypes.c_int64), ("dgate", ctypes.c_void_p),
     ]
 
 

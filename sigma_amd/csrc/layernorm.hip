@@ -29,8 +29,13 @@ __device__ __forceinline__ float wave_allsum(float v) {
 struct LnArgs {
     const float* x; const float* gamma; const float* beta; const float* dy;
     float* y; float* mean; float* rstd; float* dx; float* ws;   // ws: [nwaves][2][C]
+    const float* z; float* dz; long z_stride;                     // optional SiLU gate: y = LN(x) * silu(z)
     long M; int C; float eps;
 };
+
+__device__ __forceinline__ float sigmoid_f(float v) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-v * 1.4426950408889634f));
+}
 
 template <int NV>
 __global__ void __launch_bounds__(256) ln_fwd_kernel(const LnArgs a) {
@@ -68,6 +73,7 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(const LnArgs a) {
         }
         const float rs = rsqrtf(wave_allsum(q) * inv + a.eps);
         float* __restrict__ yr = a.y + r * C;
+        const float* __restrict__ zr = a.z ? a.z + r * a.z_stride : nullptr;
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             const int c = lane * 4 + 256 * j;
@@ -77,6 +83,11 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(const LnArgs a) {
                 o.y = (v[j].y - mu) * rs * g[j].y + b[j].y;
                 o.z = (v[j].z - mu) * rs * g[j].z + b[j].z;
                 o.w = (v[j].w - mu) * rs * g[j].w + b[j].w;
+                if (zr) {
+                    const float4 zv = *reinterpret_cast<const float4*>(zr + c);
+                    o.x *= zv.x * sigmoid_f(zv.x); o.y *= zv.y * sigmoid_f(zv.y);
+                    o.z *= zv.z * sigmoid_f(zv.z); o.w *= zv.w * sigmoid_f(zv.w);
+                }
                 *reinterpret_cast<float4*>(yr + c) = o;
             }
         }
@@ -98,6 +109,7 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const LnArgs a) {
         dg[j] = make_float4(0, 0, 0, 0);
         db[j] = make_float4(0, 0, 0, 0);
     }
+    const bool gated = a.z != nullptr;
     const float inv = 1.0f / (float)C;
     for (long r = wave; r < a.M; r += nwaves) {
         const float* __restrict__ xr = a.x + r * C;
@@ -110,8 +122,21 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const LnArgs a) {
             const int c = lane * 4 + 256 * j;
             if (c < C) {
                 const float4 xv = *reinterpret_cast<const float4*>(xr + c);
-                const float4 gv = *reinterpret_cast<const float4*>(gr + c);
+                float4 gv = *reinterpret_cast<const float4*>(gr + c);
                 xh[j] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+                if (gated) {
+                    // out = n * silu(z), n = xhat * gamma + beta:  dn = dout * silu(z),  dz = dout * n * silu'(z)
+                    const float4 zv = *reinterpret_cast<const float4*>(a.z + r * a.z_stride + c);
+                    const float4 bv = a.beta ? *reinterpret_cast<const float4*>(a.beta + c) : make_float4(0, 0, 0, 0);
+                    const float s0 = sigmoid_f(zv.x), s1_ = sigmoid_f(zv.y), s2_ = sigmoid_f(zv.z), s3 = sigmoid_f(zv.w);
+                    float4 dzv;
+                    dzv.x = gv.x * fmaf(xh[j].x, g[j].x, bv.x) * s0 * fmaf(zv.x, 1.0f - s0, 1.0f);
+                    dzv.y = gv.y * fmaf(xh[j].y, g[j].y, bv.y) * s1_ * fmaf(zv.y, 1.0f - s1_, 1.0f);
+                    dzv.z = gv.z * fmaf(xh[j].z, g[j].z, bv.z) * s2_ * fmaf(zv.z, 1.0f - s2_, 1.0f);
+                    dzv.w = gv.w * fmaf(xh[j].w, g[j].w, bv.w) * s3 * fmaf(zv.w, 1.0f - s3, 1.0f);
+                    *reinterpret_cast<float4*>(a.dz + r * C + c) = dzv;
+                    gv.x *= zv.x * s0; gv.y *= zv.y * s1_; gv.z *= zv.z * s2_; gv.w *= zv.w * s3;
+                }
                 t[j] = make_float4(gv.x * g[j].x, gv.y * g[j].y, gv.z * g[j].z, gv.w * g[j].w);
                 s1 += (t[j].x + t[j].y) + (t[j].z + t[j].w);
                 s2 += (t[j].x * xh[j].x + t[j].y * xh[j].y) + (t[j].z * xh[j].z + t[j].w * xh[j].w);
@@ -223,6 +248,8 @@ int sigma_layernorm_fwd(const sigma_layernorm_params* p, void* stream) {
     if (!p->x || !p->gamma || !p->y) return SIGMA_OPS_ERR_ARG;
     sigma::LnArgs a{};
     a.x = p->x; a.gamma = p->gamma; a.beta = p->beta; a.y = p->y; a.mean = p->mean; a.rstd = p->rstd;
+    a.z = p->gate; a.z_stride = p->gate_row_stride;
+    if (p->gate && (p->gate_row_stride % 4 != 0 || p->gate_row_stride < p->channels)) return SIGMA_OPS_ERR_ARG;
     a.M = p->rows; a.C = p->channels; a.eps = p->eps;
     const int grid = sigma::grid_blocks(p->rows);
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -241,7 +268,9 @@ int sigma_layernorm_bwd(const sigma_layernorm_params* p, void* stream) {
     if (p->rows > 0) {
         if (!p->x || !p->gamma || !p->dy || !p->mean || !p->rstd || !p->dx || !p->workspace) return SIGMA_OPS_ERR_ARG;
         sigma::LnArgs a{};
-        a.x = p->x; a.gamma = p->gamma; a.dy = p->dy; a.mean = p->mean; a.rstd = p->rstd; a.dx = p->dx; a.ws = p->workspace;
+        a.x = p->x; a.gamma = p->gamma; a.beta = p->beta; a.dy = p->dy; a.mean = p->mean; a.rstd = p->rstd; a.dx = p->dx;
+        a.ws = p->workspace; a.z = p->gate; a.z_stride = p->gate_row_stride; a.dz = p->dgate;
+        if (p->gate && (!p->dgate || p->gate_row_stride % 4 != 0 || p->gate_row_stride < p->channels)) return SIGMA_OPS_ERR_ARG;
         a.M = p->rows; a.C = p->channels; a.eps = p->eps;
         const bool ok = sigma::dispatch_nv(p->channels, [&](auto nv) {
             hipLaunchKernelGGL(sigma::ln_bwd_kernel<decltype(nv)::value>, dim3(grid), dim3(256), 0, s, a);

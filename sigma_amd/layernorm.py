@@ -15,9 +15,24 @@ import torch.nn.functional as F
 from . import _capi
 
 
+def _gate_view(z: torch.Tensor, C: int):
+    """(tensor to keep alive, row stride) of a gate whose rows of C floats are evenly spaced"""
+    if z.stride(-1) == 1 and z.dim() >= 2:
+        zs = z.reshape(-1, C) if z.is_contiguous() else None
+        if zs is not None:
+            return zs, C
+        # the chunk view xz[..., d:] of a contiguous (..., 2d) tensor: rows 2d apart
+        st = z.stride(-2)
+        ok = all(z.stride(i) == z.stride(i + 1) * z.shape[i + 1] for i in range(z.dim() - 2))
+        if ok and st % 4 == 0 and st >= C and z.data_ptr() % 16 == 0:
+            return z, st
+    zc = z.contiguous()
+    return zc, C
+
+
 class LayerNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, eps):
+    def forward(ctx, x, weight, bias, eps, gate=None):
         lib = _capi.load()
         xc = x.contiguous()
         C = xc.shape[-1]
@@ -31,19 +46,27 @@ class LayerNormFn(torch.autograd.Function):
         p.x, p.gamma, p.beta, p.y = xc.data_ptr(), weight.data_ptr(), (bias.data_ptr() if bias is not None else None), y.data_ptr()
         if need_bwd:
             p.mean, p.rstd = mean.data_ptr(), rstd.data_ptr()
+        zk = None
+        if gate is not None:
+            zk, zstride = _gate_view(gate, C)
+            p.gate, p.gate_row_stride = zk.data_ptr(), zstride
         with torch.cuda.device(x.device):
             _capi.check(lib.sigma_layernorm_fwd(ctypes.byref(p), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
                         "layernorm_fwd")
         if need_bwd:
-            ctx.save_for_backward(xc, weight, mean, rstd)
+            ctx.save_for_backward(xc, weight, mean, rstd, bias if bias is not None else weight.new_empty(0),
+                                  zk if zk is not None else weight.new_empty(0))
             ctx.has_bias = bias is not None
+            ctx.gated = gate is not None
+            ctx.gate_shape = None if gate is None else tuple(gate.shape)
+            ctx.zstride = zstride if gate is not None else 0
             ctx.eps = float(eps)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         lib = _capi.load()
-        xc, weight, mean, rstd = ctx.saved_tensors
+        xc, weight, mean, rstd, bias, zk = ctx.saved_tensors
         C = xc.shape[-1]
         rows = xc.numel() // C
         dy = dy.contiguous()
@@ -57,10 +80,15 @@ class LayerNormFn(torch.autograd.Function):
         p.x, p.gamma, p.mean, p.rstd = xc.data_ptr(), weight.data_ptr(), mean.data_ptr(), rstd.data_ptr()
         p.dy, p.dx, p.dgamma, p.workspace = dy.data_ptr(), dx.data_ptr(), dgamma.data_ptr(), ws.data_ptr()
         p.dbeta = dbeta.data_ptr() if dbeta is not None else None
+        dz = None
+        if ctx.gated:
+            dz = torch.empty(ctx.gate_shape, device=xc.device, dtype=torch.float32)
+            p.beta = bias.data_ptr() if ctx.has_bias else None
+            p.gate, p.gate_row_stride, p.dgate = zk.data_ptr(), ctx.zstride, dz.data_ptr()
         with torch.cuda.device(xc.device):
             _capi.check(lib.sigma_layernorm_bwd(ctypes.byref(p), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
                         "layernorm_bwd")
-        return dx, dgamma, dbeta, None
+        return dx, dgamma, dbeta, None, dz
 
 
 class LayerNorm(nn.LayerNorm):
@@ -72,3 +100,13 @@ class LayerNorm(nn.LayerNorm):
                 and self.weight.dtype == torch.float32 and C % 4 == 0 and 0 < C <= 2048 and x.numel() > 0):
             return LayerNormFn.apply(x, self.weight, self.bias, self.eps)
         return F.layer_norm(x, self.normalized_shape, self.weight, self.bias, self.eps)
+
+    def forward_gated(self, x: torch.Tensor, z: torch.Tensor) -> torch.Tensor:
+        """LayerNorm(x) * silu(z) in one pass (SS2D.forward, vmamba.py:1086); z may be the strided
+        second half of the in_proj output."""
+        C = x.shape[-1]
+        if (x.is_cuda and x.dtype == torch.float32 and z.dtype == torch.float32 and self.elementwise_affine
+                and len(self.normalized_shape) == 1 and C % 4 == 0 and 0 < C <= 2048 and x.numel() > 0
+                and tuple(z.shape) == tuple(x.shape)):
+            return LayerNormFn.apply(x, self.weight, self.bias, self.eps, z)
+        return self.forward(x) * F.silu(z)

@@ -38,6 +38,7 @@ from ...ss2d_fused import dwconv_silu, dwconv_silu_two_orders, selective_scan_ex
 # SIGMA_SS2D_FUSED=0 selects the plain-autograd formulation of SS2D's core (A/B measurements and
 # the fused-vs-unfused parity test); both run the same HIP scan kernels.
 _FUSED_SS2D = os.environ.get("SIGMA_SS2D_FUSED", "1") != "0"
+_FUSED_GATE = os.environ.get("SIGMA_FUSED_GATE", "1") != "0"      # out_norm * silu(z) as one HIP pass
 
 
 # --------------------------------------------------------------------------- small helpers
@@ -214,11 +215,14 @@ class SS2D(nn.Module):
             xs2 = dwconv_silu_two_orders(xi, self.conv2d.weight, self.conv2d.bias)
             y = ss2d_core_from_orders(xs2, Hq, Wq, self.x_proj_weight, self.dt_projs_weight, self.dt_projs_bias,
                                       self.A_logs, self.Ds)
-            y = self.out_norm(y).to(x.dtype)
+            if _FUSED_GATE:
+                y = self.out_norm.forward_gated(y, z).to(x.dtype)          # out_norm(y) * silu(z), one pass
+            else:
+                y = self.out_norm(y).to(x.dtype) * F.silu(z)
         else:
             y = ss2d_scan(self.act(self.conv2d(xi)), self.x_proj_weight, self.dt_projs_weight, self.dt_projs_bias,
                           self.A_logs, self.Ds, self.out_norm)
-        y = y * F.silu(z)
+            y = y * F.silu(z)
         return self.dropout(self.out_proj(y))
 
 

@@ -211,3 +211,32 @@ def test_layernorm_hip_matches_aten(shape):
         if x.dim() == 3:
             xt = x.transpose(0, 1)
             torch.testing.assert_close(ln(xt), F.layer_norm(xt, (C,), ln.weight, ln.bias, ln.eps), rtol=1e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("shape", [(2, 5, 7, 96), (1, 30, 40, 384), (3, 11, 1536)])
+def test_layernorm_with_fused_silu_gate(shape):
+    """LayerNorm(x) * silu(z) in one pass, z = the strided second half of a (…, 2C) tensor as in
+    SS2D.forward (vmamba.py:1070-1086): value, dx, dz, dgamma, dbeta vs the torch composition."""
+    import torch.nn.functional as F
+    from sigma_amd.layernorm import LayerNorm
+    C = shape[-1]
+    g = torch.Generator().manual_seed(4)
+    ln = LayerNorm(C).cuda()
+    with torch.no_grad():
+        ln.weight.copy_(1.0 + 0.3 * torch.randn(C, generator=g))
+        ln.bias.copy_(0.2 * torch.randn(C, generator=g))
+    x = torch.randn(*shape, generator=g).cuda()
+    xz = torch.randn(*shape[:-1], 2 * C, generator=g).cuda()
+    dy = torch.randn(*shape, generator=g).cuda()
+    outs = []
+    for fused in (True, False):
+        ln.zero_grad(set_to_none=True)
+        xa, xza = x.clone().requires_grad_(), xz.clone().requires_grad_()
+        z = xza[..., C:]
+        y = ln.forward_gated(xa, z) if fused else F.layer_norm(xa, (C,), ln.weight, ln.bias, ln.eps) * F.silu(z)
+        y.backward(dy)
+        outs.append([y.detach(), xa.grad, xza.grad, ln.weight.grad.clone(), ln.bias.grad.clone()])
+    rows = x.numel() // C
+    for n, a, b in zip(["y", "dx", "dxz", "dgamma", "dbeta"], *outs):
+        torch.testing.assert_close(a, b, rtol=1e-4, atol=3e-5 * (rows ** 0.5 if n.startswith("dg") or n.startswith("db") else 1.0),
+                                   msg=lambda m, n=n: f"{n}: {m}")
