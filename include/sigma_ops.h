@@ -71,6 +71,20 @@ typedef struct sigma_merge_params {
 int sigma_cross_merge_nhwc(const sigma_merge_params *params, void *stream);
 int sigma_cross_split_nhwc(const sigma_merge_params *params, void *stream);
 
+/*   sigma_transpose2d
+ *       dst[b][c][r] = src[b][r][c] with free row / batch strides (floats): the channels-last ->
+ *       channels-first copy in front of the depthwise conv (vmamba.py:1074-1075) reading the x half
+ *       of the in_proj output in place, and the inverse copy that puts dx into the x half of the
+ *       in_proj gradient (what autograd's chunk() backward does with a strided cat).               */
+typedef struct sigma_transpose_params {
+    int32_t batch, rows, cols, reserved_;
+    const float *src;      /* element (b, r, c) at src[b*src_batch_stride + r*src_row_stride + c] */
+    float *dst;            /* element (b, c, r) at dst[b*dst_batch_stride + c*dst_row_stride + r] */
+    int64_t src_batch_stride, src_row_stride, dst_batch_stride, dst_row_stride;
+} sigma_transpose_params;
+
+int sigma_transpose2d(const sigma_transpose_params *params, void *stream);
+
 /*   sigma_layernorm_fwd / sigma_layernorm_bwd
  *       nn.LayerNorm(C, eps=1e-5, affine) over the last dimension of a contiguous (rows, C) fp32
  *       tensor: every LayerNorm of the hot path (vmamba.py:617, 717, 1196-1197, 1448-1449, 1693,

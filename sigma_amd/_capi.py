@@ -82,6 +82,16 @@ class MergeParams(ctypes.Structure):
     ]
 
 
+class TransposeParams(ctypes.Structure):
+    """mirror of sigma_transpose_params (include/sigma_ops.h)"""
+    _fields_ = [
+        ("batch", ctypes.c_int32), ("rows", ctypes.c_int32), ("cols", ctypes.c_int32), ("reserved_", ctypes.c_int32),
+        ("src", ctypes.c_void_p), ("dst", ctypes.c_void_p),
+        ("src_batch_stride", ctypes.c_int64), ("src_row_stride", ctypes.c_int64),
+        ("dst_batch_stride", ctypes.c_int64), ("dst_row_stride", ctypes.c_int64),
+    ]
+
+
 class LayerNormParams(ctypes.Structure):
     """mirror of sigma_layernorm_params (include/sigma_ops.h)"""
     _fields_ = [
@@ -96,7 +106,7 @@ class LayerNormParams(ctypes.Structure):
 
 # every symbol include/sigma_ops.h declares
 OPS_SYMBOLS = ("sigma_dwconv3x3_silu_fwd", "sigma_dwconv3x3_silu_bwd", "sigma_cross_merge_nhwc", "sigma_cross_split_nhwc",
-               "sigma_layernorm_fwd", "sigma_layernorm_bwd", "sigma_layernorm_bwd_partial_rows")
+               "sigma_layernorm_fwd", "sigma_layernorm_bwd", "sigma_layernorm_bwd_partial_rows", "sigma_transpose2d")
 
 # every symbol include/sigma_scan.h declares; tests check the library exports all of them
 EXPORTED_SYMBOLS = (
@@ -154,7 +164,8 @@ def load() -> ctypes.CDLL:
         if name == "sigma_layernorm_bwd_partial_rows":
             fn.argtypes = [ctypes.c_int64]
         else:
-            st = MergeParams if "cross_" in name else LayerNormParams if "layernorm" in name else DwConvParams
+            st = (MergeParams if "cross_" in name else LayerNormParams if "layernorm" in name else
+                  TransposeParams if "transpose" in name else DwConvParams)
             fn.argtypes = [P(st), ctypes.c_void_p]
         fn.restype = ctypes.c_int
     if lib.sigma_scan_abi_version() != SIGMA_SCAN_ABI_VERSION:

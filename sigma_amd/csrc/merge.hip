@@ -111,6 +111,34 @@ __global__ void __launch_bounds__(256) cross_split_kernel(const MergeArgs a) {
     }
 }
 
+// dst[b][c][r] = src[b][r][c] for r < R, c < C with independent row / batch strides (in floats): the
+// channels-last <-> channels-first copies around the depthwise conv (vmamba.py:1074-1075 permute +
+// contiguous, and the chunk() whose backward concatenates the two gradient halves).
+struct TrArgs { const float* src; float* dst; int R, C; long src_bs, src_rs, dst_bs, dst_rs; int tiles_r, tiles_c; };
+
+__global__ void __launch_bounds__(256) transpose2d_kernel(const TrArgs a) {
+    __shared__ float t[32][33];
+    int bid = blockIdx.x;
+    const int tc = bid % a.tiles_c; bid /= a.tiles_c;
+    const int tr = bid % a.tiles_r; bid /= a.tiles_r;
+    const int b = bid;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float* __restrict__ s = a.src + (long)b * a.src_bs;
+    float* __restrict__ d = a.dst + (long)b * a.dst_bs;
+    const int r0 = tr * 32, c0 = tc * 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + ty + 8 * i, c = c0 + tx;
+        t[ty + 8 * i][tx] = (r < a.R && c < a.C) ? s[(long)r * a.src_rs + c] : 0.0f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i, r = r0 + tx;
+        if (r < a.R && c < a.C) d[(long)c * a.dst_rs + r] = t[tx][ty + 8 * i];
+    }
+}
+
 bool grid_for(const sigma_merge_params* p, unsigned* grid) {
     if (!p || p->batch < 0 || p->channels <= 0 || p->height <= 0 || p->width <= 0) return false;
     const long n = (long)p->batch * ((p->height + kP - 1) / kP) * ((p->width + kP - 1) / kP) * ((p->channels + kC - 1) / kC);
@@ -144,6 +172,20 @@ int sigma_cross_split_nhwc(const sigma_merge_params* p, void* stream) {
     sigma::MergeArgs a{};
     a.dy = p->nhwc; a.g2 = p->planes2; a.B = p->batch; a.d = p->channels; a.H = p->height; a.W = p->width;
     hipLaunchKernelGGL(sigma::cross_split_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    return hipGetLastError() == hipSuccess ? SIGMA_OPS_OK : SIGMA_OPS_ERR_LAUNCH;
+}
+
+int sigma_transpose2d(const sigma_transpose_params* p, void* stream) {
+    if (!p || p->batch < 0 || p->rows <= 0 || p->cols <= 0) return SIGMA_OPS_ERR_ARG;
+    if (p->batch == 0) return SIGMA_OPS_OK;
+    if (!p->src || !p->dst) return SIGMA_OPS_ERR_ARG;
+    sigma::TrArgs a{};
+    a.src = p->src; a.dst = p->dst; a.R = p->rows; a.C = p->cols;
+    a.src_bs = p->src_batch_stride; a.src_rs = p->src_row_stride; a.dst_bs = p->dst_batch_stride; a.dst_rs = p->dst_row_stride;
+    a.tiles_r = (p->rows + 31) / 32; a.tiles_c = (p->cols + 31) / 32;
+    const long n = (long)p->batch * a.tiles_r * a.tiles_c;
+    if (n > 2147483647L) return SIGMA_OPS_ERR_ARG;
+    hipLaunchKernelGGL(sigma::transpose2d_kernel, dim3((unsigned)n), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     return hipGetLastError() == hipSuccess ? SIGMA_OPS_OK : SIGMA_OPS_ERR_LAUNCH;
 }
 

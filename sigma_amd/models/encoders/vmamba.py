@@ -33,12 +33,14 @@ import torch.nn.functional as F
 import os
 
 from ...selective_scan import selective_scan_fn
-from ...ss2d_fused import dwconv_silu, dwconv_silu_two_orders, selective_scan_ext, ss2d_core, ss2d_core_from_orders
+from ...ss2d_fused import (dwconv_silu, dwconv_silu_two_orders, selective_scan_ext, split_xz, ss2d_core,
+                           ss2d_core_from_orders)
 
 # SIGMA_SS2D_FUSED=0 selects the plain-autograd formulation of SS2D's core (A/B measurements and
 # the fused-vs-unfused parity test); both run the same HIP scan kernels.
 _FUSED_SS2D = os.environ.get("SIGMA_SS2D_FUSED", "1") != "0"
 _FUSED_GATE = os.environ.get("SIGMA_FUSED_GATE", "1") != "0"      # out_norm * silu(z) as one HIP pass
+_FUSED_SPLIT = os.environ.get("SIGMA_FUSED_SPLIT", "1") != "0"    # chunk + permute as one tiled transpose
 
 
 # --------------------------------------------------------------------------- small helpers
@@ -207,8 +209,11 @@ class SS2D(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:       # x: (B, H, W, C)
         xz = self.in_proj(x)
-        xi, z = xz.chunk(2, dim=-1)
-        xi = xi.permute(0, 3, 1, 2).contiguous()                             # (B, d, H, W)
+        if _FUSED_SS2D and _FUSED_SPLIT and xz.is_cuda and xz.dtype == torch.float32:
+            xi, z = split_xz(xz)                                             # (B, d, H, W), view (B, H, W, d)
+        else:
+            xi, z = xz.chunk(2, dim=-1)
+            xi = xi.permute(0, 3, 1, 2).contiguous()                         # (B, d, H, W)
         if _FUSED_SS2D and xi.is_cuda:
             # depthwise conv + SiLU + both scan orders in one HIP pass, then the fused scan core
             Bq, dq, Hq, Wq = xi.shape

@@ -109,6 +109,54 @@ def dwconv_silu(x, weight, bias):
     return DwConvSiLUTwoOrdersFn.apply(x, weight, bias, 1).view(B, d, H, W)
 
 
+def _transpose2d(src, dst, B, R, C, src_bs, src_rs, dst_bs, dst_rs):
+    import ctypes
+    from . import _capi
+    p = _capi.TransposeParams()
+    p.batch, p.rows, p.cols = B, R, C
+    p.src, p.dst = src.data_ptr(), dst.data_ptr()
+    p.src_batch_stride, p.src_row_stride, p.dst_batch_stride, p.dst_row_stride = src_bs, src_rs, dst_bs, dst_rs
+    with torch.cuda.device(src.device):
+        _capi.check(_capi.load().sigma_transpose2d(ctypes.byref(p), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                    "transpose2d")
+
+
+class SplitXZFn(torch.autograd.Function):
+    """xz (B, H, W, 2d) -> (x channels-first (B, d, H, W) contiguous, z = the view xz[..., d:]).
+
+    Reference: ``x, z = xz.chunk(2, dim=-1); x = x.permute(0, 3, 1, 2).contiguous()`` (vmamba.py:1070-1075).
+    Forward is one tiled transpose reading the x half in place; backward writes dx (channels-first) into
+    the x half of ONE gradient buffer with the inverse transpose and copies dz into the z half, instead
+    of autograd's strided cat of a permuted view."""
+
+    @staticmethod
+    def forward(ctx, xz):
+        B, H, W, d2 = xz.shape
+        d, L = d2 // 2, H * W
+        xz = xz.contiguous()
+        x = torch.empty(B, d, H, W, device=xz.device, dtype=xz.dtype)
+        _transpose2d(xz, x, B, L, d, L * d2, d2, d * L, L)
+        ctx.dims = (B, H, W, d)
+        z = xz[..., d:]
+        return x, z
+
+    @staticmethod
+    def backward(ctx, dx, dz):
+        B, H, W, d = ctx.dims
+        L = H * W
+        dxz = torch.empty(B, H, W, 2 * d, device=dx.device, dtype=dx.dtype)
+        _transpose2d(dx.contiguous(), dxz, B, d, L, d * L, L, L * 2 * d, 2 * d)
+        if dz is None:
+            dxz[..., d:].zero_()
+        else:
+            dxz[..., d:].copy_(dz)
+        return dxz
+
+
+def split_xz(xz):
+    return SplitXZFn.apply(xz)
+
+
 class SelectiveScanExtFn(torch.autograd.Function):
     """selective scan with the operator extensions of include/sigma_scan.h under autograd:
     ``rev_mask`` (bit g: group g runs backwards by addressing) and ``u_gshift`` (group g reads the

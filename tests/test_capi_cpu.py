@@ -38,7 +38,7 @@ def test_struct_layout_matches_header(tmp_path):
     lines = []
     structs = (("sigma_scan_fwd_params", _capi.FwdParams), ("sigma_scan_bwd_params", _capi.BwdParams),
                ("sigma_dwconv_params", _capi.DwConvParams), ("sigma_merge_params", _capi.MergeParams),
-               ("sigma_layernorm_params", _capi.LayerNormParams))
+               ("sigma_layernorm_params", _capi.LayerNormParams), ("sigma_transpose_params", _capi.TransposeParams))
     for cname, cls in structs:
         lines.append(f'printf("%s %zu\\n", "{cname}", sizeof({cname}));')
         for fname, _ in cls._fields_:

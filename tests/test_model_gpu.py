@@ -240,3 +240,24 @@ def test_layernorm_with_fused_silu_gate(shape):
     for n, a, b in zip(["y", "dx", "dxz", "dgamma", "dbeta"], *outs):
         torch.testing.assert_close(a, b, rtol=1e-4, atol=3e-5 * (rows ** 0.5 if n.startswith("dg") or n.startswith("db") else 1.0),
                                    msg=lambda m, n=n: f"{n}: {m}")
+
+
+@pytest.mark.parametrize("shape", [(2, 15, 20, 48), (1, 7, 9, 200), (2, 30, 40, 384)])
+def test_split_xz_matches_chunk_permute(shape):
+    """SplitXZFn (tiled transposes) vs xz.chunk + permute + contiguous (vmamba.py:1070-1075), with grads."""
+    from sigma_amd.ss2d_fused import split_xz
+    B, H, W, d = shape
+    g = torch.Generator().manual_seed(6)
+    xz = torch.randn(B, H, W, 2 * d, generator=g).cuda()
+    gx = torch.randn(B, d, H, W, generator=g).cuda()
+    gz = torch.randn(B, H, W, d, generator=g).cuda()
+    a = xz.clone().requires_grad_()
+    x1, z1 = split_xz(a)
+    (x1 * gx).sum().backward(retain_graph=True)
+    (z1 * gz).sum().backward()
+    b = xz.clone().requires_grad_()
+    x2, z2 = b.chunk(2, dim=-1)
+    x2 = x2.permute(0, 3, 1, 2).contiguous()
+    ((x2 * gx).sum() + (z2 * gz).sum()).backward()
+    assert torch.equal(x1, x2) and torch.equal(z1, z2) and x1.is_contiguous()
+    torch.testing.assert_close(a.grad, b.grad, rtol=0, atol=0)
