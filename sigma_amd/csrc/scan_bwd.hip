@@ -26,6 +26,8 @@
 #include "scan_device.h"
 #include "scan_launch.h"
 
+#include <atomic>
+
 namespace sigma {
 
 namespace {
@@ -465,10 +467,13 @@ static hipError_t launch_bwd_t(const BwdArgs& a, hipStream_t stream) {
     const size_t lds = bwd_lds_bytes(T, a.f.R, a.f.NB, a.f.N, a.slab2 != 0);
     const int grid = a.f.rowblocks * a.f.batch;
     auto kern = scan_bwd_kernel<io_t, T, GLDS>;
-    if (lds > 48 * 1024) {
+    // raise the dynamic-LDS cap once per kernel and size (not per launch: the call is host-expensive)
+    static std::atomic<size_t> lds_cap{48 * 1024};
+    if (lds > lds_cap.load(std::memory_order_relaxed)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
+        lds_cap.store(lds, std::memory_order_relaxed);
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(a.f.R * 64), lds, stream, a);
     hipError_t e = hipGetLastError();

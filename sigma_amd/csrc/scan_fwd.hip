@@ -29,6 +29,8 @@
 #include "scan_device.h"
 #include "scan_launch.h"
 
+#include <atomic>
+
 namespace sigma {
 
 namespace {
@@ -281,10 +283,13 @@ static hipError_t launch_fwd_t(const FwdArgs& a, hipStream_t stream) {
     const size_t lds = fwd_lds_bytes(T, a.R, a.W, a.NB, a.N);
     const int grid = a.rowblocks * a.batch;
     auto kern = scan_fwd_kernel<io_t, T, GLDS, PREFETCH>;
-    if (lds > 48 * 1024) {
+    // raise the dynamic-LDS cap once per kernel and size (not per launch: the call is host-expensive)
+    static std::atomic<size_t> lds_cap{48 * 1024};
+    if (lds > lds_cap.load(std::memory_order_relaxed)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
+        lds_cap.store(lds, std::memory_order_relaxed);
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(a.R * a.W * 64), lds, stream, a);
     return hipGetLastError();

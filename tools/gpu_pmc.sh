@@ -6,7 +6,6 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG/$SHAPES
 mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
-rocprofv3 -L > $OUT/counters_list.txt 2>&1
 run() {  # name, counters...
   local name=$1; shift
   timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -o p -- python $R/tools/scan_bench.py --shapes $SHAPES --iters 3 > $OUT/$name.log 2>&1

@@ -1,18 +1,22 @@
 #!/bin/bash
-# One GPU-box round trip: parity tests, operator microbench, headline bench, rocprofv3 kernel stats.
-# Usage (from the repo root on the GPU box): bash tools/gpu_round.sh [tag]
+# One full GPU-box round trip: smoke, parity tests, operator microbench, headline bench, rocprofv3 kernel
+# stats of both, PMC traffic of the dominant scan shape.  Usage: bash tools/gpu_round.sh [tag]
 TAG=${1:-r01}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd $R
 export TMPDIR=/tmp
-( time timeout 900 python -m pytest tests -m gpu -x -q ) > $OUT/pytest_gpu.log 2>&1
-tail -3 $OUT/pytest_gpu.log
+( time timeout 300 python -c "import __graft_entry__ as g; g.smoke()" ) > $OUT/smoke.log 2>&1; tail -2 $OUT/smoke.log
+( time timeout 900 python -m pytest tests -m gpu -x -q ) > $OUT/pytest_gpu.log 2>&1; tail -3 $OUT/pytest_gpu.log
 timeout 300 python tools/scan_bench.py --iters 10 --out $OUT/scan_bench.jsonl > $OUT/scan_bench.log 2>&1
-cat $OUT/scan_bench.log | cut -c1-400
-( time timeout 600 python bench.py --steps 3 --warmup 1 --kernel-report $OUT/kernels.json ) > $OUT/bench.log 2>&1
-tail -5 $OUT/bench.log
+( time timeout 600 python bench.py --kernel-report $OUT/kernels.json ) > $OUT/bench.log 2>&1; grep "^{" $OUT/bench.log | cut -c1-900
 cd /tmp
-timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/prof_scan -o scan -- python $R/tools/scan_bench.py --shapes enc_s0,enc_s2,dec_s0,conmb_s0 --iters 5 > $OUT/rocprof_scan.log 2>&1
-ls -R $OUT/prof_scan | head -20
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_scan -o scan -- python $R/tools/scan_bench.py --shapes enc_s0,enc_s2_b16,enc_s0_b8,dec_s0_b8,conmb_s0_b8 --iters 5 > $OUT/rocprof_scan.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench -o bench -- python $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline > $OUT/rocprof_bench.log 2>&1
+cd $R
+python tools/prof_summary.py $OUT/prof_bench/bench_kernel_trace.csv --last-ms 700 --top 60 > $OUT/bench_last700ms_kernel_stats.txt 2>&1
+python tools/prof_summary.py $OUT/prof_scan/scan_kernel_stats.csv --top 12 > $OUT/scan_bench_kernel_stats.txt 2>&1
+rm -f $OUT/prof_bench/bench_kernel_trace.csv $OUT/prof_scan/scan_kernel_trace.csv
+bash tools/gpu_pmc.sh $TAG/pmc enc_s2_b16 traffic > $OUT/pmc.log 2>&1; tail -6 $OUT/pmc.log
+head -14 $OUT/bench_last700ms_kernel_stats.txt | cut -c1-160
