@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SIGMA_SCAN_ABI_VERSION 3
+#define SIGMA_SCAN_ABI_VERSION 4
 
 /* dtype of u, delta, B, C, out, dout, du, ddelta  (input_t of the reference,
  * selective_scan.cpp:174: float / half / bfloat16).  A, D, delta_bias, x, dA,
@@ -60,11 +60,15 @@ enum sigma_status {
  * private scratch between this library's fwd and bwd (the reference never documents or tests
  * them; its own bwd only accepts the x of its own fwd).  Layout used here -- the kernels tile the
  * sequence by 1280 / 640 / 320 / 256 elements, which 2048 is not a multiple of:
- *     checkpoint j = the N states of a row after element min(seqlen, (j+1)*1280) - 1,
- *     for j < ceil(seqlen / 1280), stored at x[b, r, j / 2, 2*n + (j % 2)].
- * 2 * ceil(seqlen/2048) >= ceil(seqlen/1280), so it always fits.  Unused slots are not written. */
+ *     checkpoint j = the N states of a row after element min(seqlen, (j+1)*pitch) - 1,
+ *     for j < ceil(seqlen / pitch), stored at x[(b*dim + r) * x_row_stride + j*N + n].
+ * Default pitch 1280 and x_row_stride = n_chunks*2*N (the reference shape; 2*ceil(seqlen/2048) >=
+ * ceil(seqlen/1280), so it always fits).  Callers that allocate x themselves may ask for the fine
+ * pitch 640 (ckpt_pitch field) with x_row_stride >= ceil(seqlen/640)*N: the backward then needs no
+ * forward sweep at all with 640-element tiles.  Unused slots are not written. */
 #define SIGMA_SCAN_CHUNK 2048
 #define SIGMA_SCAN_CKPT_PITCH 1280
+#define SIGMA_SCAN_CKPT_PITCH_FINE 640
 /* dstate limit of the reference (selective_scan.cpp:10,201). */
 #define SIGMA_SCAN_MAX_DSTATE 256
 
@@ -88,6 +92,9 @@ typedef struct sigma_scan_fwd_params {
      *      flip share one physical copy of x. */
     uint32_t rev_group_mask;
     int32_t u_group_shift;
+    int32_t ckpt_pitch;        /* 0 = SIGMA_SCAN_CKPT_PITCH (1280); 640 = fine checkpoints (see above) */
+    int32_t reserved0_;
+    int64_t x_row_stride;      /* floats per (batch, row) of x; 0 = n_chunks * 2 * dstate */
     /* inputs */
     const void *u;            /* (B, dim, L)        io_dtype */
     const void *delta;        /* (B, dim, L)        io_dtype */
@@ -98,8 +105,8 @@ typedef struct sigma_scan_fwd_params {
     const float *delta_bias;  /* (dim) or NULL      f32      */
     /* outputs */
     void *out;                /* (B, dim, L)        io_dtype */
-    float *x;                 /* (B, dim, n_chunks, 2N) f32 contiguous, or NULL (inference):
-                                 state checkpoints every 1280 elements, layout above */
+    float *x;                 /* (B, dim, n_chunks, 2N) f32 (or x_row_stride floats per row), or NULL
+                                 (inference): state checkpoints, layout above */
     /* element strides */
     int64_t u_batch_stride, u_d_stride;
     int64_t delta_batch_stride, delta_d_stride;

@@ -14,9 +14,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SIGMA_HIP_LIB lets a benchmark A/B an experimental build of the same ABI; default is the in-tree library
 LIB_PATH = os.environ.get("SIGMA_HIP_LIB") or os.path.join(_HERE, "lib", "libsigma_hip.so")
 
-SIGMA_SCAN_ABI_VERSION = 3
+SIGMA_SCAN_ABI_VERSION = 4
 SIGMA_SCAN_CHUNK = 2048
 SIGMA_SCAN_CKPT_PITCH = 1280
+SIGMA_SCAN_CKPT_PITCH_FINE = 640
 SIGMA_SCAN_MAX_DSTATE = 256
 
 DTYPE_F32, DTYPE_F16, DTYPE_BF16 = 0, 1, 2
@@ -32,6 +33,7 @@ class FwdParams(ctypes.Structure):
         ("dstate", ctypes.c_int32), ("n_groups", ctypes.c_int32), ("n_chunks", ctypes.c_int32),
         ("io_dtype", ctypes.c_int32), ("delta_softplus", ctypes.c_int32),
         ("rev_group_mask", ctypes.c_uint32), ("u_group_shift", ctypes.c_int32),
+        ("ckpt_pitch", ctypes.c_int32), ("reserved0_", ctypes.c_int32), ("x_row_stride", ctypes.c_int64),
         ("u", ctypes.c_void_p), ("delta", ctypes.c_void_p), ("A", ctypes.c_void_p),
         ("B", ctypes.c_void_p), ("C", ctypes.c_void_p), ("D", ctypes.c_void_p),
         ("delta_bias", ctypes.c_void_p),

@@ -52,6 +52,17 @@ int check_fwd(const sigma_scan_fwd_params* p, bool need_out, bool need_ptrs = tr
                     p->seqlen);
     if (p->rev_group_mask != 0 && (p->n_groups > 32 || (p->n_groups < 32 && (p->rev_group_mask >> p->n_groups) != 0)))
         return fail(SIGMA_ERR_BAD_SHAPE, "rev_group_mask 0x%x names groups >= n_groups (%d)", p->rev_group_mask, p->n_groups);
+    if (p->ckpt_pitch != 0 && p->ckpt_pitch != SIGMA_SCAN_CKPT_PITCH && p->ckpt_pitch != SIGMA_SCAN_CKPT_PITCH_FINE)
+        return fail(SIGMA_ERR_BAD_SHAPE, "ckpt_pitch must be 0, %d or %d (got %d)", SIGMA_SCAN_CKPT_PITCH,
+                    SIGMA_SCAN_CKPT_PITCH_FINE, p->ckpt_pitch);
+    {
+        const int pitch = p->ckpt_pitch ? p->ckpt_pitch : SIGMA_SCAN_CKPT_PITCH;
+        const int64_t need = (int64_t)((p->seqlen + pitch - 1) / pitch) * p->dstate;
+        const int64_t have = p->x_row_stride ? p->x_row_stride : (int64_t)p->n_chunks * 2 * p->dstate;
+        if (p->x && have < need)
+            return fail(SIGMA_ERR_BAD_SHAPE, "x_row_stride %lld too small for %lld checkpoint floats per row",
+                        (long long)have, (long long)need);
+    }
     if (p->u_group_shift < 0 || p->u_group_shift > 5)
         return fail(SIGMA_ERR_BAD_SHAPE, "u_group_shift must be in [0, 5] (got %d)", p->u_group_shift);
     if (p->batch == 0 || p->seqlen == 0 || !need_ptrs) return SIGMA_OK;
@@ -83,6 +94,8 @@ sigma::FwdArgs make_fwd_args(const sigma_scan_fwd_params* p, int R, int W, int N
     a.R = R; a.W = W; a.NB = NB;
     a.rev_mask = p->rev_group_mask;
     a.u_gshift = p->u_group_shift;
+    a.ckpt_pitch = p->ckpt_pitch ? p->ckpt_pitch : sigma::kCkptPitch;
+    a.x_rs = p->x_row_stride ? p->x_row_stride : (long)p->n_chunks * 2 * p->dstate;
     a.u_bs = p->u_batch_stride; a.u_ds = p->u_d_stride; a.dt_bs = p->delta_batch_stride; a.dt_ds = p->delta_d_stride;
     a.A_ds = p->A_d_stride; a.A_ns = p->A_dstate_stride;
     a.B_bs = p->B_batch_stride; a.B_gs = p->B_group_stride; a.B_ns = p->B_dstate_stride;
@@ -136,14 +149,16 @@ Plan plan_fwd(const sigma_scan_fwd_params* p, bool vec) {
     // when forced ("fwd_items" = 20) until it measures faster than two 640 tiles.
     static const int cand[] = {10, 5, 4};
     Plan pl;
-    const int forced_items = g_opt_fwd_items.load();
+    const bool fine = p->ckpt_pitch == SIGMA_SCAN_CKPT_PITCH_FINE;    // tiles must divide 640: T in {10, 5}
+    int forced_items = g_opt_fwd_items.load();
+    if (fine && (forced_items == 20 || forced_items == 4)) forced_items = 0;
     // measured (tools/bwd_variants.py): with 16 states and long sequences the 1280-element tile wins
     // (half as many tile starts whose u/delta latency is exposed; 805 vs 961 us at (8,768,19200));
     // short sequences and few-state scans prefer 640-element tiles with the register prefetch
-    const bool long_rows = (long)p->batch * p->dim >= 12L * kCUs && p->dstate > 8 && p->seqlen >= 10240;
+    const bool long_rows = !fine && (long)p->batch * p->dim >= 12L * kCUs && p->dstate > 8 && p->seqlen >= 10240;
     pl.items = forced_items == 20 ? 20
              : (forced_items == 0 && long_rows) ? 20
-             : pick_items(p->seqlen, cand, 3, fwd_cost_per_element, forced_items);
+             : pick_items(p->seqlen, cand, fine ? 2 : 3, fwd_cost_per_element, forced_items);
     pl.glds = glds_ok(p, vec);
     const int rpg = p->dim / p->n_groups;
     const long total_rows = (long)p->batch * p->dim;
@@ -195,7 +210,10 @@ Plan plan_fwd(const sigma_scan_fwd_params* p, bool vec) {
 Plan plan_bwd(const sigma_scan_fwd_params* p, bool vec) {
     static const int cand[] = {10, 5, 4};
     Plan pl;
-    pl.items = pick_items(p->seqlen, cand, 3, bwd_cost_per_element, g_opt_bwd_items.load());
+    const bool fine = p->ckpt_pitch == SIGMA_SCAN_CKPT_PITCH_FINE;
+    int forced_bitems = g_opt_bwd_items.load();
+    if (fine && forced_bitems == 4) forced_bitems = 0;
+    pl.items = pick_items(p->seqlen, cand, fine ? 2 : 3, bwd_cost_per_element, forced_bitems);
     pl.glds = glds_ok(p, vec);
     pl.tiles = 1;
     pl.slab2 = false;
@@ -334,8 +352,8 @@ int sigma_selective_scan_bwd(const sigma_scan_bwd_params* q, void* stream) {
     if (p->batch == 0 || p->seqlen == 0) return SIGMA_OK;
     if (!q->dout || !q->du || !q->ddelta || !q->dA || !q->dB || !q->dC)
         return fail(SIGMA_ERR_NULL_ARG, "dout/du/ddelta/dA/dB/dC must be non-NULL device pointers");
-    if (p->seqlen > SIGMA_SCAN_CKPT_PITCH && !p->x)
-        return fail(SIGMA_ERR_NULL_ARG, "x (forward checkpoints) is required when seqlen > %d", SIGMA_SCAN_CKPT_PITCH);
+    if (p->seqlen > (p->ckpt_pitch ? p->ckpt_pitch : SIGMA_SCAN_CKPT_PITCH) && !p->x)
+        return fail(SIGMA_ERR_NULL_ARG, "x (forward checkpoints) is required when seqlen > the checkpoint pitch");
     if ((p->D == nullptr) != (q->dD == nullptr) || (p->delta_bias == nullptr) != (q->ddelta_bias == nullptr))
         return fail(SIGMA_ERR_NULL_ARG, "dD / ddelta_bias must be given exactly when D / delta_bias are");
     const bool vec = vec_ok_bwd(q);

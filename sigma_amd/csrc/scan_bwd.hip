@@ -78,7 +78,9 @@ __device__ __forceinline__ void stage_tile(float* __restrict__ dst, const io_t* 
 template <typename io_t, int T, bool GLDS, bool REV>
 __device__ __forceinline__ void scan_bwd_body(const BwdArgs& q, float* smem, int b, int row0, int g) {
     constexpr int TILE = 64 * T;
-    constexpr int TPS = kCkptPitch / TILE;            // tiles per checkpoint span
+    constexpr int TPSMAX = kCkptPitch / TILE;         // LDS sizing: tiles per span at the default pitch
+    const int TPS = q.f.ckpt_pitch / TILE;            // tiles per checkpoint span (1 with the fine pitch at T = 10)
+    const int pitch = q.f.ckpt_pitch;
     constexpr int VW = vec_width<T>::value;
     const FwdArgs& p = q.f;
     const int R = blockDim.x >> 6;
@@ -87,7 +89,7 @@ __device__ __forceinline__ void scan_bwd_body(const BwdArgs& q, float* smem, int
     float* sBC = smem;                                // [2][2][NB][TILE]
     float* sRed = sBC + 2 * bufsz;                    // [R][2][TILE] per-row dB/dC terms of one state
     float* sX0 = sRed + (q.slab2 ? 2 : 1) * R * 2 * TILE;   // [R][TPS][N] state at tile start
-    float* sRv = sX0 + R * TPS * N;                   // [R][N] reverse carry a*dx of the tile to the right
+    float* sRv = sX0 + R * TPSMAX * N;                // [R][N] reverse carry a*dx of the tile to the right
     float* sdA = sRv + R * N;                         // [R][N]
     float* sA = sdA + R * N;                          // [R][N] A[r, n]
 
@@ -111,7 +113,7 @@ __device__ __forceinline__ void scan_bwd_body(const BwdArgs& q, float* smem, int
     const float* __restrict__ A_row = p.A + (long)r * p.A_ds;
     const float bias = p.bias ? p.bias[r] : 0.0f;
     const float Dd = p.D ? p.D[r] : 0.0f;
-    const float* __restrict__ x_row = p.x ? p.x + ((long)b * p.dim + r) * (long)p.n_chunks * 2 * N : nullptr;
+    const float* __restrict__ x_row = p.x ? p.x + ((long)b * p.dim + r) * p.x_rs : nullptr;
 
     const long ws_slab = (q.P > 1)
         ? ((((long)((row0 - g * p.rows_per_group) / R) * p.batch + b) * p.G + g) * (long)N * L) : 0;
@@ -124,10 +126,10 @@ __device__ __forceinline__ void scan_bwd_body(const BwdArgs& q, float* smem, int
     float dD_acc = 0.0f, dbias_acc = 0.0f;
 
     const int nsb = (N + NB - 1) / NB;
-    const int nspans = (L + kCkptPitch - 1) / kCkptPitch;
+    const int nspans = (L + pitch - 1) / pitch;
     auto tiles_in_span = [&](int s) {
-        const int rem = L - s * kCkptPitch;
-        return rem >= kCkptPitch ? TPS : (rem + TILE - 1) / TILE;
+        const int rem = L - s * pitch;
+        return rem >= pitch ? TPS : (rem + TILE - 1) / TILE;
     };
     StagePlan<T, REV> plan;
     if constexpr (GLDS) plan.init(NB, 1, L);
@@ -157,7 +159,7 @@ __device__ __forceinline__ void scan_bwd_body(const BwdArgs& q, float* smem, int
         // ================= phase F: state at the start of every tile of this span
         for (int n = lane; n < N; n += 64) {
             float x0 = 0.0f;
-            if (s > 0 && x_row) { const int ci = s - 1; x0 = x_row[((long)(ci >> 1) * N + n) * 2 + (ci & 1)]; }
+            if (s > 0 && x_row) x0 = x_row[(long)(s - 1) * N + n];
             sX0[(wave * TPS + 0) * N + n] = x0;
         }
         for (int j = 0; j + 1 < ntc; ++j) {

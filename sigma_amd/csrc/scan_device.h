@@ -375,7 +375,8 @@ struct StagePlan {
 };
 
 // ------------------------------------------------------------------ kernel args
-constexpr int kCkptPitch = 1280;   // elements between state checkpoints in x (see include/sigma_scan.h)
+constexpr int kCkptPitch = 1280;   // default elements between state checkpoints in x (see include/sigma_scan.h)
+constexpr int kCkptPitchFine = 640; // fine pitch: one checkpoint per 640-tile, no forward sweep in bwd
 
 struct FwdArgs {
     const void* u; const void* delta; const float* A; const void* B; const void* C;
@@ -386,6 +387,8 @@ struct FwdArgs {
     int NB;               // states staged per step
     unsigned rev_mask;    // bit g set: group g runs over the sequence in reverse memory order
     int u_gshift;         // u rows of group g are those of group (g >> u_gshift): directions share copies of x
+    int ckpt_pitch;       // elements between checkpoints (1280 or 640)
+    long x_rs;            // floats per row of x: checkpoint j of row (b, r) at x[(b*dim + r)*x_rs + j*N + n]
     long u_bs, u_ds, dt_bs, dt_ds, A_ds, A_ns;
     long B_bs, B_gs, B_ns, C_bs, C_gs, C_ns, o_bs, o_ds;
 };

@@ -117,7 +117,7 @@ __device__ __forceinline__ void scan_fwd_body(const FwdArgs& p, float* smem, int
     const io_t* __restrict__ Cg = reinterpret_cast<const io_t*>(p.C) + (long)b * p.C_bs + (long)g * p.C_gs;
     const float bias = p.bias ? p.bias[r] : 0.0f;
     const float Dd = p.D ? p.D[r] : 0.0f;
-    float* __restrict__ x_row = p.x ? p.x + ((long)b * p.dim + r) * (long)p.n_chunks * 2 * N : nullptr;
+    float* __restrict__ x_row = p.x ? p.x + ((long)b * p.dim + r) * p.x_rs : nullptr;
 
     if (wt == 0) {
         const float* __restrict__ A_row = p.A + (long)r * p.A_ds;
@@ -174,8 +174,8 @@ __device__ __forceinline__ void scan_fwd_body(const FwdArgs& p, float* smem, int
 
         // checkpoint slot of this tile's end state (every kCkptPitch elements and at the very end)
         const int lend = (l0 + TILE < L) ? (l0 + TILE) : L;
-        const bool ckpt = x_row != nullptr && l0 < L && ((lend % kCkptPitch) == 0 || lend == L);
-        const int cidx = (lend - 1) / kCkptPitch;
+        const bool ckpt = x_row != nullptr && l0 < L && ((lend % p.ckpt_pitch) == 0 || lend == L);
+        const int cidx = (lend - 1) / p.ckpt_pitch;
         const float* sRunIn = sRun + (st & 1) * R * N + wr * N;
         float* sRunOut = sRun + ((st + 1) & 1) * R * N + wr * N;
 
@@ -248,7 +248,7 @@ __device__ __forceinline__ void scan_fwd_body(const FwdArgs& p, float* smem, int
                 }
                 if (lane == 63) {
                     if (wt == W - 1) sRunOut[n] = x;    // state after this super-tile
-                    if (ckpt) x_row[((long)(cidx >> 1) * N + n) * 2 + (cidx & 1)] = x;
+                    if (ckpt) x_row[(long)cidx * N + n] = x;
                 }
             }
             __syncthreads();                            // staged block landed; current block consumed

@@ -93,6 +93,8 @@ def _fill_fwd(fp: _capi.FwdParams, u, delta, A, B, C, D_, delta_bias_, out, x, d
               rev_mask=0, u_gshift=0):
     batch, dim, seqlen, dstate, n_groups = sizes
     fp.rev_group_mask, fp.u_group_shift = int(rev_mask), int(u_gshift)
+    if x is not None and x.dim() == 3:              # fine checkpoints: (B, dim, ceil(L/640) * N)
+        fp.ckpt_pitch, fp.x_row_stride = _capi.SIGMA_SCAN_CKPT_PITCH_FINE, x.stride(1)
     fp.batch, fp.dim, fp.seqlen, fp.dstate, fp.n_groups = batch, dim, seqlen, dstate, n_groups
     fp.n_chunks = (seqlen + _capi.SIGMA_SCAN_CHUNK - 1) // _capi.SIGMA_SCAN_CHUNK
     fp.io_dtype = _DTYPES[u.dtype]
@@ -118,16 +120,22 @@ def fwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B: torch.Tensor, 
 
 
 def fwd_ext(u, delta, A, B, C, D_, delta_bias_, delta_softplus, nrows: int = 1, rev_mask: int = 0,
-            u_gshift: int = 0, need_x: bool = True) -> List[torch.Tensor]:
+            u_gshift: int = 0, need_x: bool = True, fine_ckpt: bool = False) -> List[torch.Tensor]:
     """``fwd`` plus the two extensions of include/sigma_scan.h used by the fused SS2D path:
     ``rev_mask`` (bit g: group g scans backwards, by addressing) and ``u_gshift`` (group g reads
-    the u rows of group g >> u_gshift; u has dim >> u_gshift rows)."""
+    the u rows of group g >> u_gshift; u has dim >> u_gshift rows).  ``fine_ckpt``: x is allocated
+    as (B, dim, ceil(L/640) * N) with one state checkpoint per 640 elements (include/sigma_scan.h),
+    which spares ``bwd_ext`` its forward sweep; such an x is only valid for ``bwd_ext``."""
     lib = _capi.load()
     sizes = _check_common(u, delta, A, B, C, D_, delta_bias_, nrows, u_gshift)
     batch, dim, seqlen, dstate, _ = sizes
     n_chunks = (seqlen + _capi.SIGMA_SCAN_CHUNK - 1) // _capi.SIGMA_SCAN_CHUNK
     out = torch.empty_like(delta)                                   # selective_scan.cpp:226
-    x = torch.empty((batch, dim, n_chunks, dstate * 2), device=u.device, dtype=torch.float32)  # :228
+    if fine_ckpt:
+        ncp = (seqlen + _capi.SIGMA_SCAN_CKPT_PITCH_FINE - 1) // _capi.SIGMA_SCAN_CKPT_PITCH_FINE
+        x = torch.empty((batch, dim, max(ncp, 1) * dstate), device=u.device, dtype=torch.float32)
+    else:
+        x = torch.empty((batch, dim, n_chunks, dstate * 2), device=u.device, dtype=torch.float32)  # :228
     if batch == 0 or seqlen == 0:
         return [out, x]
     fp = _capi.FwdParams()
@@ -167,8 +175,12 @@ def bwd_ext(u, delta, A, B, C, D_, delta_bias_, dout, x_, delta_softplus, nrows:
         _check(x_ is not None, "x is required when seqlen > 2048")   # :320 (here: already above 1280)
     if x_ is not None:
         _check(x_.dtype == torch.float32 and x_.is_cuda and x_.is_contiguous(), "x must be a contiguous float32 GPU tensor")
-        _check(tuple(x_.shape) == (batch, dim, n_chunks, 2 * dstate),
-               "x must have shape (batch_size, dim, n_chunks, 2 * dstate)")
+        if x_.dim() == 3:        # fine checkpoints of fwd_ext(fine_ckpt=True)
+            ncp = (seqlen + _capi.SIGMA_SCAN_CKPT_PITCH_FINE - 1) // _capi.SIGMA_SCAN_CKPT_PITCH_FINE
+            _check(tuple(x_.shape) == (batch, dim, max(ncp, 1) * dstate), "fine-checkpoint x must be (batch, dim, ceil(L/640)*dstate)")
+        else:
+            _check(tuple(x_.shape) == (batch, dim, n_chunks, 2 * dstate),
+                   "x must have shape (batch_size, dim, n_chunks, 2 * dstate)")
     du = torch.empty_like(delta)                                     # :329-337 (== empty_like(u) in the reference)
     ddelta = torch.empty_like(delta)
     dA = torch.zeros_like(A)

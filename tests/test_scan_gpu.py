@@ -202,18 +202,31 @@ def test_real_stage_shapes_forward_and_backward(shape):
 def test_checkpoint_tensor_shape_and_documented_layout():
     """x has the reference's SHAPE (batch, dim, ceil(L/2048), 2N) (selective_scan.cpp:225-228); its
     contents are this library's private fwd->bwd scratch, documented in include/sigma_scan.h:
-    checkpoint j = state after element min(L, (j+1)*1280)-1 at x[b, r, j//2, 2n + j%2]."""
+    checkpoint j = state after element min(L, (j+1)*1280)-1 at x[b, r].flatten()[j*N + n]; with
+    fine_ckpt the pitch is 640 and x is (B, dim, ceil(L/640)*N)."""
     so = _oracle()
     batch, KD, L, N, G = 2, 8, 5000, 4, 2
     u, delta, A, B, C, D, bias, _ = _model_like(batch, KD, L, N, G, seed=3)
     dev = "cuda"
     out, x = _core().fwd(u.to(dev), delta.to(dev), A.to(dev), B.to(dev), C.to(dev), D.to(dev), bias.to(dev), True, 1)
     assert x.shape == (batch, KD, 3, 2 * N) and x.dtype == torch.float32
-    x = x.cpu().view(batch, KD, 3, N, 2)
-    for j, end in enumerate([1280, 2560, 3840, 5000]):
-        _, st = so.selective_scan_oracle(u[..., :end], delta[..., :end], A, B[..., :end], C[..., :end], D, bias, True,
-                                         acc64=True, return_last_state=True)
-        torch.testing.assert_close(x[:, :, j // 2, :, j % 2], st, rtol=1e-3, atol=1e-4)
+    x = x.cpu().reshape(batch, KD, -1)
+    args = [t.to(dev) for t in (u, delta, A, B, C, D, bias)]
+    out2, xf = _core().fwd_ext(*args, True, fine_ckpt=True)
+    assert xf.shape == (batch, KD, 8 * N) and torch.equal(out2, out)
+    xf = xf.cpu()
+    for pitch, xt in ((1280, x), (640, xf)):
+        for j in range((L + pitch - 1) // pitch):
+            end = min(L, (j + 1) * pitch)
+            _, st = so.selective_scan_oracle(u[..., :end], delta[..., :end], A, B[..., :end], C[..., :end], D, bias, True,
+                                             acc64=True, return_last_state=True)
+            torch.testing.assert_close(xt[:, :, j * N:(j + 1) * N], st, rtol=1e-3, atol=1e-4)
+    # the backward gives the same gradients from either checkpoint tensor
+    dout = torch.randn(batch, KD, L).to(dev)
+    g1 = _core().bwd_ext(*args, dout, x.to(dev).view(batch, KD, 3, 2 * N), True)
+    g2 = _core().bwd_ext(*args, dout, xf.to(dev), True)
+    for a, b in zip(g1, g2):
+        torch.testing.assert_close(a, b, rtol=2e-4, atol=1e-5 + 1e-5 * float(b.abs().max()))
 
 
 def _run_hip_ext(u, delta, A, B, C, D, bias, dout, rev_mask=0, u_gshift=0, dout_gshift=0):
