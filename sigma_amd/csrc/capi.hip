@@ -196,7 +196,7 @@ Plan plan_fwd(const sigma_scan_fwd_params* p, bool vec) {
             // a CU with few waves runs each of them faster, but not proportionally
             // (with <= 8 states the staging share per row matters more than the interleaving: 16 rows win)
             const double occ = p->dstate > 8 ? (0.35 + 0.65 * (double)(waves * wgpc) / 16.0) : 1.0;
-            const double per_step = occ * (1.0 + 2.0 / R + (W > 1 ? 0.15 : 0.0)) * ((wgpc >= 2 && p->dstate > 8) ? 0.85 : 1.0);
+            const double per_step = occ * (1.0 + 2.0 / R + (W > 1 ? 0.15 : 0.0)) * ((wgpc >= 2 && p->dstate > 8 && p->seqlen < 10240) ? 0.85 : 1.0);   // long rows: 16-row workgroups measured equal or better
             const double cost = (double)rounds * nsuper * per_step;
             if (cost < best) { best = cost; pl.rows = R; pl.tiles = W; pl.nb = NB; }
         }

@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--sweep", action="store_true")
     ap.add_argument("--dtype", default="float32")
     ap.add_argument("--out", default="")
+    ap.add_argument("--fine", action="store_true", help="fine (640) checkpoints, as the fused model path uses")
     a = ap.parse_args()
     dt = getattr(torch, a.dtype)
     es = 4 if dt == torch.float32 else 2
@@ -92,7 +93,10 @@ def main():
     for name in a.shapes.split(","):
         shape = SHAPES[name]
         u, delta, A, Bm, Cm, D, bias, dout = make(shape, dt)
-        _, x = core.fwd(u, delta, A, Bm, Cm, D, bias, True, 1)
+        if a.fine:
+            _, x = core.fwd_ext(u, delta, A, Bm, Cm, D, bias, True, fine_ckpt=True)
+        else:
+            _, x = core.fwd(u, delta, A, Bm, Cm, D, bias, True, 1)
         fb, bb = fwd_bytes(*shape, s=es), bwd_bytes(*shape, s=es)
         geos = [(0, 0, 0)]
         if a.sweep:
@@ -102,7 +106,10 @@ def main():
             _capi.set_option("fwd_items", items)
             _capi.set_option("fwd_waves", waves)
             _capi.set_option("fwd_tiles", tiles)
-            t = time_call(lambda: core.fwd(u, delta, A, Bm, Cm, D, bias, True, 1), a.iters)
+            if a.fine:
+                t = time_call(lambda: core.fwd_ext(u, delta, A, Bm, Cm, D, bias, True, fine_ckpt=True), a.iters)
+            else:
+                t = time_call(lambda: core.fwd(u, delta, A, Bm, Cm, D, bias, True, 1), a.iters)
             rec.update(fwd_us=t * 1e6, fwd_GBs=fb / t / 1e9, fwd_frac_of_8TBs=fb / t / HBM_PEAK)
             if items in (0, 5, 10) and tiles <= 1:
                 _capi.set_option("bwd_items", items)
