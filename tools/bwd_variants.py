@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""A/B of backward launch variants on the dominant shapes (options of sigma_scan_set_option)."""
+"""A/B of launch variants (options of sigma_scan_set_option) on the dominant shapes, forward and backward.
+SIGMA_HIP_LIB=<variant .so> (python -m sigma_amd.build --variant ...) compares builds of the same ABI."""
 import json, os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,8 +10,8 @@ from tools.scan_bench import SHAPES, make, time_call, bwd_bytes, fwd_bytes
 
 VARIANTS = [dict(), dict(bwd_nb=2), dict(bwd_nb=2, bwd_slab2=1), dict(bwd_waves=6), dict(bwd_waves=6, bwd_nb=2),
             dict(bwd_waves=8, bwd_nb=2, bwd_slab2=1), dict(bwd_items=5), dict(bwd_items=5, bwd_slab2=1)]
-FV = [dict()]
-VARIANTS = [dict(), dict(bwd_waves=12), dict(bwd_waves=8)]
+FV = [dict(), dict(fwd_prefetch=2), dict(fwd_waves=16), dict(fwd_waves=4), dict(fwd_items=20), dict(fwd_items=5)]
+VARIANTS = [dict(), dict(bwd_waves=8), dict(bwd_nb=2, bwd_slab2=1), dict(bwd_items=5)]
 for name in sys.argv[1:] or ["enc_s2_b16", "enc_s0_b8", "dec_s0_b8"]:
     shape = SHAPES[name]
     u, delta, A, Bm, Cm, D, bias, dout = make(shape)
