@@ -53,6 +53,8 @@ def parse():
     ap.add_argument("--classes", type=int, default=40)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--conv-autotune", action="store_true", help="torch.backends.cudnn.benchmark = True (slow start)")
+    ap.add_argument("--force-ddp", action="store_true",
+                    help="single process: still create the RCCL process group and wrap the model in DDP (plumbing check)")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU oracle work")
     ap.add_argument("--kernel-report", default="", help="write the per-kernel-shape table (json) here")
     return ap.parse_args()
@@ -166,8 +168,10 @@ def main():
     # for this model's ~60 convolution configurations runs for more than 15 minutes before the
     # first step returns (measured), so the default here is MIOpen's immediate mode.
     torch.backends.cudnn.benchmark = bool(a.conv_autotune)
-    if world > 1:
+    ddp = world > 1 or a.force_ddp
+    if ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
 
     from sigma_amd import selective_scan_cuda_core as core
@@ -193,7 +197,7 @@ def main():
         os.chdir(cwd)
     model.to(dev).train()
     opt = ts.make_optimizer(model)
-    net = ts.wrap_ddp(model, dev, world)                     # train.py:107
+    net = ts.wrap_ddp(model, dev, world)           # train.py:107
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     rgb = torch.randn(a.batch, 3, a.height, a.width, generator=g).to(dev)
     mx = torch.randn(a.batch, 3, a.height, a.width, generator=g).to(dev)
@@ -249,7 +253,7 @@ def main():
                                 loss=round(float(loss.item()), 4)),
                     roofline=roof, roofline_fwd=roof_fwd, cpu_baseline=cpu)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if ddp:
         dist.destroy_process_group()
 
 

@@ -43,9 +43,14 @@ def make_optimizer(model: nn.Module, lr: float = 6e-5, weight_decay: float = 0.0
     return torch.optim.AdamW(group_weight(model, lr), lr=lr, betas=(0.9, 0.999), weight_decay=weight_decay)
 
 
+def _distributed() -> bool:
+    """collectives are used exactly when a process group exists (world size 1 included: plumbing checks)"""
+    return dist.is_available() and dist.is_initialized()
+
+
 def wrap_ddp(model: nn.Module, device: torch.device, world: int) -> nn.Module:
     """train.py:107.  find_unused_parameters=False: every parameter must receive a gradient."""
-    if world <= 1:
+    if not _distributed():
         return model
     ids = [device.index] if device.type == "cuda" else None
     return nn.parallel.DistributedDataParallel(model, device_ids=ids, output_device=ids[0] if ids else None,
@@ -57,7 +62,7 @@ def make_step(net: nn.Module, opt, batch: Tuple[torch.Tensor, ...], world: int) 
     def step():
         opt.zero_grad(set_to_none=True)
         loss = net(*batch)
-        if world > 1:                                        # train.py:168 (logging all-reduce)
+        if _distributed():                                   # train.py:168 (logging all-reduce)
             red = loss.detach().clone()
             dist.all_reduce(red, op=dist.ReduceOp.SUM)
         loss.backward()
@@ -67,7 +72,7 @@ def make_step(net: nn.Module, opt, batch: Tuple[torch.Tensor, ...], world: int) 
 
 
 def _sync(device: torch.device, world: int) -> None:
-    if world > 1:
+    if _distributed():
         dist.barrier()
     if device.type == "cuda":
         torch.cuda.synchronize(device)
@@ -87,7 +92,7 @@ def timed_steps(step: Callable[[], torch.Tensor], steps: int, warmup: int, devic
         loss = step()
     _sync(device, world)
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if _distributed():
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
