@@ -32,8 +32,9 @@ namespace sigma {
 
 namespace {
 
-// Stage B (and C) rows of states [n0, n0+nbn) of ONE tile into dst laid out [arr][NB][TILE].
-template <typename io_t, int T, bool GLDS>
+// Register path of the B/C staging (16-bit IO types, unaligned tensors): rows of states [n0, n0+nbn)
+// of ONE tile into dst laid out [arr][NB][TILE]; the f32 / aligned case uses StagePlan (scan_device.h).
+template <typename io_t, int T>
 __device__ __forceinline__ void stage_tile(float* __restrict__ dst, const io_t* __restrict__ Bg,
                                            const io_t* __restrict__ Cg, long B_ns, long C_ns, int n0, int nbn, int NB,
                                            int tile, int L, bool rev, bool vec, bool with_c) {
@@ -41,35 +42,18 @@ __device__ __forceinline__ void stage_tile(float* __restrict__ dst, const io_t* 
     constexpr int CPR = TILE / 4;
     const int total = (with_c ? 2 : 1) * NB * CPR;
     const int l0 = tile * TILE;
-    if constexpr (GLDS) {
-        const int lane = threadIdx.x & 63;
-        const int wave = threadIdx.x >> 6;
-        const int nwaves = blockDim.x >> 6;
-        for (int unit = wave; unit * 64 < total; unit += nwaves) {
-            const int ci = unit * 64 + lane;
-            const int row = ci / CPR;                  // arr * NB + nn
-            const int c4 = (ci - row * CPR) * 4;
-            const int arr = row / NB;
-            const int nn = row - arr * NB;
-            const int m = rev ? (L - l0 - TILE + c4) : (l0 + c4);
-            const bool ok = ci < total && nn < nbn && m >= 0 && m < L;
-            const io_t* __restrict__ src = (arr == 0 ? Bg + (long)(n0 + nn) * B_ns : Cg + (long)(n0 + nn) * C_ns) + m;
-            if (ok) __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + unit * 256), 16, 0, 0);
+    for (int ci = threadIdx.x; ci < total; ci += blockDim.x) {
+        const int row = ci / CPR;                      // arr * NB + nn
+        const int c4 = (ci - row * CPR) * 4;
+        const int arr = row / NB;
+        const int nn = row - arr * NB;
+        const int m = rev ? (L - l0 - TILE + c4) : (l0 + c4);
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (nn < nbn && m < L && m + 4 > 0) {
+            const io_t* __restrict__ srow = arr == 0 ? Bg + (long)(n0 + nn) * B_ns : Cg + (long)(n0 + nn) * C_ns;
+            load4_guard<io_t>(srow, m, L, vec, v);
         }
-    } else {
-        for (int ci = threadIdx.x; ci < total; ci += blockDim.x) {
-            const int row = ci / CPR;
-            const int c4 = (ci - row * CPR) * 4;
-            const int arr = row / NB;
-            const int nn = row - arr * NB;
-            const int m = rev ? (L - l0 - TILE + c4) : (l0 + c4);
-            float v[4] = {0.f, 0.f, 0.f, 0.f};
-            if (nn < nbn && m < L && m + 4 > 0) {
-                const io_t* __restrict__ srow = arr == 0 ? Bg + (long)(n0 + nn) * B_ns : Cg + (long)(n0 + nn) * C_ns;
-                load4_guard<io_t>(srow, m, L, vec, v);
-            }
-            *reinterpret_cast<float4*>(dst + (long)ci * 4) = make_float4(v[0], v[1], v[2], v[3]);
-        }
+        *reinterpret_cast<float4*>(dst + (long)ci * 4) = make_float4(v[0], v[1], v[2], v[3]);
     }
 }
 
@@ -141,7 +125,7 @@ __device__ __forceinline__ void scan_bwd_body(const BwdArgs& q, float* smem, int
             plan.issue(dst, reinterpret_cast<const float*>(Bg), reinterpret_cast<const float*>(Cg), (int)p.B_ns, (int)p.C_ns,
                        n0, nbn, tile, L, NB * TILE, with_c);
         } else {
-            stage_tile<io_t, T, false>(dst, Bg, Cg, p.B_ns, p.C_ns, n0, nbn, NB, tile, L, REV, vec, with_c);
+            stage_tile<io_t, T>(dst, Bg, Cg, p.B_ns, p.C_ns, n0, nbn, NB, tile, L, REV, vec, with_c);
         }
     };
 

@@ -35,55 +35,32 @@ namespace sigma {
 
 namespace {
 
-// Stage B and C rows of states [n0, n0+nbn) for the W tiles starting at tile index tile0 into
-// `dst` laid out [arr = B,C][NB][W][TILE] (floats, memory order).
-template <typename io_t, int T, bool GLDS>
+// Register path of the B/C staging (16-bit IO types, unaligned tensors): rows of states [n0, n0+nbn)
+// for the W tiles starting at tile index tile0 into `dst` laid out [arr = B,C][NB][W][TILE] (floats,
+// memory order).  The f32 / aligned case streams with global_load_lds instead (StagePlan, scan_device.h).
+template <typename io_t, int T>
 __device__ __forceinline__ void stage_bc(float* __restrict__ dst, const io_t* __restrict__ Bg,
                                          const io_t* __restrict__ Cg, long B_ns, long C_ns, int n0, int nbn, int NB,
-                                         int W, int tile0, int L, bool rev, bool vec, bool with_c) {
+                                         int W, int tile0, int L, bool rev, bool vec) {
     constexpr int TILE = 64 * T;
     constexpr int CPR = TILE / 4;                      // 16-byte chunks per (state, tile) row
     const int rows = NB * W;                           // rows per array in the LDS image
-    const int total = (with_c ? 2 : 1) * rows * CPR;
-    const int nthreads = blockDim.x;
-    if constexpr (GLDS) {
-        // units of 64 chunks (1 KiB): LDS destination = wave-uniform base + lane * 16
-        const int lane = threadIdx.x & 63;
-        const int wave = threadIdx.x >> 6;
-        const int nwaves = nthreads >> 6;
-        for (int unit = wave; unit * 64 < total; unit += nwaves) {
-            const int ci = unit * 64 + lane;
-            const int row = ci / CPR;                  // arr * rows + nn * W + w
-            const int c4 = (ci - row * CPR) * 4;
-            const int arr = row / rows;
-            const int rr = row - arr * rows;
-            const int nn = rr / W;
-            const int w = rr - nn * W;
-            const int l0 = (tile0 + w) * TILE;
-            const int m = rev ? (L - l0 - TILE + c4) : (l0 + c4);
-            const bool ok = ci < total && nn < nbn && m >= 0 && m < L;   // L % 4 == 0: whole chunk in range
-            const io_t* __restrict__ src = (arr == 0 ? Bg + (long)(n0 + nn) * B_ns : Cg + (long)(n0 + nn) * C_ns) + m;
-            if (ok) {
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + unit * 256), 16, 0, 0);
-            }
+    const int total = 2 * rows * CPR;
+    for (int ci = threadIdx.x; ci < total; ci += blockDim.x) {
+        const int row = ci / CPR;                      // arr * rows + nn * W + w
+        const int c4 = (ci - row * CPR) * 4;
+        const int arr = row / rows;
+        const int rr = row - arr * rows;
+        const int nn = rr / W;
+        const int w = rr - nn * W;
+        const int l0 = (tile0 + w) * TILE;
+        const int m = rev ? (L - l0 - TILE + c4) : (l0 + c4);
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (nn < nbn && m < L && m + 4 > 0) {
+            const io_t* __restrict__ srow = arr == 0 ? Bg + (long)(n0 + nn) * B_ns : Cg + (long)(n0 + nn) * C_ns;
+            load4_guard<io_t>(srow, m, L, vec, v);
         }
-    } else {
-        for (int ci = threadIdx.x; ci < total; ci += nthreads) {
-            const int row = ci / CPR;
-            const int c4 = (ci - row * CPR) * 4;
-            const int arr = row / rows;
-            const int rr = row - arr * rows;
-            const int nn = rr / W;
-            const int w = rr - nn * W;
-            const int l0 = (tile0 + w) * TILE;
-            const int m = rev ? (L - l0 - TILE + c4) : (l0 + c4);
-            float v[4] = {0.f, 0.f, 0.f, 0.f};
-            if (nn < nbn && m < L && m + 4 > 0) {
-                const io_t* __restrict__ srow = arr == 0 ? Bg + (long)(n0 + nn) * B_ns : Cg + (long)(n0 + nn) * C_ns;
-                load4_guard<io_t>(srow, m, L, vec, v);
-            }
-            *reinterpret_cast<float4*>(dst + (long)ci * 4) = make_float4(v[0], v[1], v[2], v[3]);
-        }
+        *reinterpret_cast<float4*>(dst + (long)ci * 4) = make_float4(v[0], v[1], v[2], v[3]);
     }
 }
 
@@ -143,7 +120,7 @@ __device__ __forceinline__ void scan_fwd_body(const FwdArgs& p, float* smem, int
             plan.issue(dst, reinterpret_cast<const float*>(Bg), reinterpret_cast<const float*>(Cg), (int)p.B_ns, (int)p.C_ns,
                        n0, nbn, tile0, L, NB * W * TILE, true);
         } else {
-            stage_bc<io_t, T, false>(dst, Bg, Cg, p.B_ns, p.C_ns, n0, nbn, NB, W, tile0, L, REV, vec, true);
+            stage_bc<io_t, T>(dst, Bg, Cg, p.B_ns, p.C_ns, n0, nbn, NB, W, tile0, L, REV, vec);
         }
     };
     // ---- prologue: first B/C block and first u/delta segment
