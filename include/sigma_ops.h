@@ -5,7 +5,7 @@
  * have no counterpart in the reference's native code (which only has the selective-scan kernels):
  *
  *   sigma_dwconv3x3_silu_fwd / _bwd
- *       SS2D.forward, vmamba.py:1075-1077:  x = x.permute(0,3,1,2).contiguous(); x = act(conv2d(x))
+ *       SS2D.forward, vmamba.py:1071-1072:  x = x.permute(0,3,1,2).contiguous(); x = act(conv2d(x))
  *       with conv2d = nn.Conv2d(d, d, 3, padding=1, groups=d, bias) (vmamba.py:679-683), fused with
  *       the layout half of CrossScan (vmamba.py:80-89): the activation is written once in row-major
  *       and once in column-major sequence order, which is all the scan kernels need (the two
@@ -34,7 +34,7 @@ typedef struct sigma_dwconv_params {
     int32_t batch, channels, height, width;
     int32_t n_orders;      /* 2: out2/g2 hold the row-major AND the column-major sequence (SS2D);
                               1: row-major only, i.e. plain conv + SiLU (CroMB / ConMB, vmamba.py:1629-1630,
-                              1262-1263) */
+                              1271-1272) */
     int32_t reserved_;
     const float *x;        /* (B, d, H, W)   input of the convolution                              */
     const float *weight;   /* (d, 1, 3, 3)                                                         */
@@ -73,7 +73,7 @@ int sigma_cross_split_nhwc(const sigma_merge_params *params, void *stream);
 
 /*   sigma_transpose2d
  *       dst[b][c][r] = src[b][r][c] with free row / batch strides (floats): the channels-last ->
- *       channels-first copy in front of the depthwise conv (vmamba.py:1074-1075) reading the x half
+ *       channels-first copy in front of the depthwise conv (vmamba.py:1070-1071) reading the x half
  *       of the in_proj output in place, and the inverse copy that puts dx into the x half of the
  *       in_proj gradient (what autograd's chunk() backward does with a strided cat).               */
 typedef struct sigma_transpose_params {
@@ -107,7 +107,7 @@ typedef struct sigma_layernorm_params {
     float *dgamma;         /* bwd out (C)                     */
     float *dbeta;          /* bwd out (C) or NULL             */
     float *workspace;      /* bwd scratch                     */
-    /* optional fused gate of SS2D.forward (vmamba.py:1086: y = out_norm(y) * act(z)):
+    /* optional fused gate of SS2D.forward (vmamba.py:1077: y = out_norm(y) * act(z)):
      * y = LayerNorm(x) * silu(gate);  gate rows are gate_row_stride floats apart (z is the second
      * half of the in_proj output), dgate is contiguous (rows, C).  NULL gate = plain LayerNorm.  */
     const float *gate;

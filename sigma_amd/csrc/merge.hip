@@ -112,7 +112,7 @@ __global__ void __launch_bounds__(256) cross_split_kernel(const MergeArgs a) {
 }
 
 // dst[b][c][r] = src[b][r][c] for r < R, c < C with independent row / batch strides (in floats): the
-// channels-last <-> channels-first copies around the depthwise conv (vmamba.py:1074-1075 permute +
+// channels-last <-> channels-first copies around the depthwise conv (vmamba.py:1070-1071 permute +
 // contiguous, and the chunk() whose backward concatenates the two gradient halves).
 struct TrArgs { const float* src; float* dst; int R, C; long src_bs, src_rs, dst_bs, dst_rs; int tiles_r, tiles_c; };
 

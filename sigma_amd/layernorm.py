@@ -102,7 +102,7 @@ class LayerNorm(nn.LayerNorm):
         return F.layer_norm(x, self.normalized_shape, self.weight, self.bias, self.eps)
 
     def forward_gated(self, x: torch.Tensor, z: torch.Tensor) -> torch.Tensor:
-        """LayerNorm(x) * silu(z) in one pass (SS2D.forward, vmamba.py:1086); z may be the strided
+        """LayerNorm(x) * silu(z) in one pass (SS2D.forward, vmamba.py:1077); z may be the strided
         second half of the in_proj output."""
         C = x.shape[-1]
         if (x.is_cuda and x.dtype == torch.float32 and z.dtype == torch.float32 and self.elementwise_affine

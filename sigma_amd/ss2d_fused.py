@@ -51,7 +51,7 @@ def _two_orders(x4: torch.Tensor) -> torch.Tensor:
 class DwConvSiLUTwoOrdersFn(torch.autograd.Function):
     """xs2 = [silu(dwconv3x3(x)) row-major, the same column-major]  (B, d, H, W) -> (B, 2, d, H*W).
 
-    Reference: SS2D.forward vmamba.py:1075-1077 + the layout half of CrossScan (:80-89); kernels in
+    Reference: SS2D.forward vmamba.py:1071-1072 + the layout half of CrossScan (:80-89); kernels in
     sigma_amd/csrc/dwconv.hip, C ABI in include/sigma_ops.h."""
 
     @staticmethod
@@ -127,7 +127,7 @@ def _transpose2d(src, dst, B, R, C, src_bs, src_rs, dst_bs, dst_rs):
 class SplitXZFn(torch.autograd.Function):
     """xz (B, H, W, 2d) -> (x channels-first (B, d, H, W) contiguous, z = the view xz[..., d:]).
 
-    Reference: ``x, z = xz.chunk(2, dim=-1); x = x.permute(0, 3, 1, 2).contiguous()`` (vmamba.py:1070-1075).
+    Reference: ``x, z = xz.chunk(2, dim=-1); x = x.permute(0, 3, 1, 2).contiguous()`` (vmamba.py:1070-1071).
     Forward is one tiled transpose reading the x half in place; backward writes dx (channels-first) into
     the x half of ONE gradient buffer with the inverse transpose and copies dz into the z half, instead
     of autograd's strided cat of a permuted view."""

@@ -102,7 +102,7 @@ def test_fused_ss2d_core_equals_plain_autograd_formulation(shape):
 @pytest.mark.parametrize("shape", [(2, 24, 15, 20), (1, 7, 33, 65), (3, 16, 120, 160), (2, 5, 1, 9), (1, 3, 46, 80)])
 def test_dwconv_silu_two_orders_matches_torch(shape):
     """HIP depthwise 3x3 conv + SiLU + both scan orders (include/sigma_ops.h) vs nn.Conv2d + F.silu +
-    view/transpose in plain torch (vmamba.py:1075-1077, 80-89): values, dx, dW, dbias."""
+    view/transpose in plain torch (vmamba.py:1071-1072, 80-89): values, dx, dW, dbias."""
     import torch.nn.functional as F
     from sigma_amd.ss2d_fused import dwconv_silu, dwconv_silu_two_orders
     B, d, H, W = shape
@@ -216,7 +216,7 @@ def test_layernorm_hip_matches_aten(shape):
 @pytest.mark.parametrize("shape", [(2, 5, 7, 96), (1, 30, 40, 384), (3, 11, 1536)])
 def test_layernorm_with_fused_silu_gate(shape):
     """LayerNorm(x) * silu(z) in one pass, z = the strided second half of a (…, 2C) tensor as in
-    SS2D.forward (vmamba.py:1070-1086): value, dx, dz, dgamma, dbeta vs the torch composition."""
+    SS2D.forward (vmamba.py:1070-1077): value, dx, dz, dgamma, dbeta vs the torch composition."""
     import torch.nn.functional as F
     from sigma_amd.layernorm import LayerNorm
     C = shape[-1]
@@ -244,7 +244,7 @@ def test_layernorm_with_fused_silu_gate(shape):
 
 @pytest.mark.parametrize("shape", [(2, 15, 20, 48), (1, 7, 9, 200), (2, 30, 40, 384)])
 def test_split_xz_matches_chunk_permute(shape):
-    """SplitXZFn (tiled transposes) vs xz.chunk + permute + contiguous (vmamba.py:1070-1075), with grads."""
+    """SplitXZFn (tiled transposes) vs xz.chunk + permute + contiguous (vmamba.py:1070-1071), with grads."""
     from sigma_amd.ss2d_fused import split_xz
     B, H, W, d = shape
     g = torch.Generator().manual_seed(6)
