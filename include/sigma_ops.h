@@ -87,8 +87,8 @@ int sigma_transpose2d(const sigma_transpose_params *params, void *stream);
 
 /*   sigma_layernorm_fwd / sigma_layernorm_bwd
  *       nn.LayerNorm(C, eps=1e-5, affine) over the last dimension of a contiguous (rows, C) fp32
- *       tensor: every LayerNorm of the hot path (vmamba.py:617, 717, 1196-1197, 1448-1449, 1693,
- *       1783, 1797; MambaDecoder.py:18, 41, 93).  C % 4 == 0, C <= 2048.
+ *       tensor: every LayerNorm of the hot path (vmamba.py:617, 724, 1183-1184, 1448-1449, 1693,
+ *       1783, 1797; MambaDecoder.py:18, 41, 85).  C % 4 == 0, C <= 2048.
  *       bwd: dx fully written; dgamma / dbeta fully written (deterministic two-stage column sums
  *       through `workspace` of sigma_layernorm_bwd_partial_rows(rows) * 2 * C floats).
  *       bwd with a gate needs beta as well (the normalised value is recomputed).                  */

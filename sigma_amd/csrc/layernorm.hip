@@ -1,8 +1,8 @@
 // layernorm.hip -- LayerNorm over the channel (last) dimension, forward and backward.
 //
 // Reference: every nn.LayerNorm on the hot path -- VSSBlock.norm (vmamba.py:1693), SS2D.out_norm
-// (vmamba.py:717), PatchMerging2D.norm (:617), the fusion blocks' out_norm_{1,2} (:1448-1449, 1196-1197)
-// and the decoder norms (MambaDecoder.py:18,41,93, vmamba.py:1783,1797); eps 1e-5, affine.
+// (vmamba.py:724), PatchMerging2D.norm (:617), the fusion blocks' out_norm_{1,2} (:1448-1449, 1183-1184)
+// and the decoder norms (MambaDecoder.py:18,41,85, vmamba.py:1783,1797); eps 1e-5, affine.
 // ATen's ROCm kernels spend 240 us on the backward of a (19200 x 384) call (three kernels, profile
 // r01); the op is a pure HBM stream: forward 1 read + 1 write, backward 2 reads + 1 write.
 //
