@@ -6,7 +6,7 @@
  *
  *   sigma_dwconv3x3_silu_fwd / _bwd
  *       SS2D.forward, vmamba.py:1071-1072:  x = x.permute(0,3,1,2).contiguous(); x = act(conv2d(x))
- *       with conv2d = nn.Conv2d(d, d, 3, padding=1, groups=d, bias) (vmamba.py:679-683), fused with
+ *       with conv2d = nn.Conv2d(d, d, 3, padding=1, groups=d, bias) (vmamba.py:683-691), fused with
  *       the layout half of CrossScan (vmamba.py:80-89): the activation is written once in row-major
  *       and once in column-major sequence order, which is all the scan kernels need (the two
  *       flipped directions are read backwards, see sigma_scan.h rev_group_mask).

@@ -1,6 +1,6 @@
 // dwconv.hip -- depthwise 3x3 convolution + SiLU of SS2D, fused with the CrossScan layout step.
 //
-// Reference (models/encoders/vmamba.py:1071-1072, 679-683):
+// Reference (models/encoders/vmamba.py:1071-1072, 683-691):
 //     x = x.permute(0, 3, 1, 2).contiguous();  x = self.act(self.conv2d(x))       # Conv2d(d, d, 3, pad 1, groups=d) + SiLU
 // followed by CrossScan's four permuted copies (vmamba.py:80-98).  On MI355X all of it is HBM-bound
 // stencil / transpose work, so it is one pass: read the (B, d, H, W) plane once, write the activation in
