@@ -43,10 +43,12 @@ HBM_PEAK_GBS = 8000.0        # MI355X spec (MI355X_MICROARCH.md); ~6300 GB/s is 
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks = GPUs of this node (default: the launcher's WORLD_SIZE, else 1)")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=8, help="per-GPU batch of RGB-X pairs")
+    ap.add_argument("--batch", "--per-gpu-batch", dest="batch", type=int, default=8,
+                    help="per-GPU batch of RGB-X pairs (8 = weak scaling from the reference's batch_size 8; "
+                         "1 = the reference's faithful 8-GPU split, dataloader/dataloader.py:79)")
     ap.add_argument("--backbone", default="sigma_small")
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--width", type=int, default=640)
@@ -157,11 +159,18 @@ def cpu_baseline(backbone, H, W, budget_s):
 
 def main():
     a = parse()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    from sigma_amd import train_step as ts
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    plan = ts.launch_plan(a.gpus, os.environ, torch.cuda.device_count() if torch.cuda.is_available() else 0,
+                          sys.argv[1:], os.path.abspath(__file__), port)
+    if plan[0] == "spawn":           # `python bench.py --gpus N`: become N ranks (one per GPU, RCCL)
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        raise SystemExit(subprocess.call(plan[1], env=env))
+    _, world, rank, local = plan
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     # train.py:57 sets cudnn.benchmark = True; on ROCm that is MIOpen's exhaustive find mode, which
@@ -175,7 +184,6 @@ def main():
         dist.init_process_group(backend="nccl", rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
 
     from sigma_amd import selective_scan_cuda_core as core
-    from sigma_amd import train_step as ts
     from sigma_amd.models.builder import EncoderDecoder
 
     timer = KernelTimer()
@@ -197,17 +205,17 @@ def main():
         os.chdir(cwd)
     model.to(dev).train()
     opt = ts.make_optimizer(model)
-    net = ts.wrap_ddp(model, dev, world)           # train.py:107
+    net = ts.wrap_ddp(model, dev)           # train.py:107
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     rgb = torch.randn(a.batch, 3, a.height, a.width, generator=g).to(dev)
     mx = torch.randn(a.batch, 3, a.height, a.width, generator=g).to(dev)
     label = torch.randint(0, a.classes, (a.batch, a.height, a.width), generator=g).to(dev)
-    step = ts.make_step(net, opt, (rgb, mx, label), world)
+    step = ts.make_step(net, opt, (rgb, mx, label))
 
     def start_timers():
         timer.enabled = True
 
-    elapsed, loss = ts.timed_steps(step, a.steps, a.warmup, dev, world, on_timed_start=start_timers)
+    elapsed, loss = ts.timed_steps(step, a.steps, a.warmup, dev, on_timed_start=start_timers)
     timer.enabled = False
 
     if rank == 0:

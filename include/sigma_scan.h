@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SIGMA_SCAN_ABI_VERSION 4
+#define SIGMA_SCAN_ABI_VERSION 5
 
 /* dtype of u, delta, B, C, out, dout, du, ddelta  (input_t of the reference,
  * selective_scan.cpp:174: float / half / bfloat16).  A, D, delta_bias, x, dA,
@@ -63,12 +63,15 @@ enum sigma_status {
  *     checkpoint j = the N states of a row after element min(seqlen, (j+1)*pitch) - 1,
  *     for j < ceil(seqlen / pitch), stored at x[(b*dim + r) * x_row_stride + j*N + n].
  * Default pitch 1280 and x_row_stride = n_chunks*2*N (the reference shape; 2*ceil(seqlen/2048) >=
- * ceil(seqlen/1280), so it always fits).  Callers that allocate x themselves may ask for the fine
- * pitch 640 (ckpt_pitch field) with x_row_stride >= ceil(seqlen/640)*N: the backward then needs no
- * forward sweep at all with 640-element tiles.  Unused slots are not written. */
+ * ceil(seqlen/1280), so it always fits).  Callers that allocate x themselves may ask for a fine
+ * pitch 640 or 320 (ckpt_pitch field) with x_row_stride >= ceil(seqlen/pitch)*N: the backward then
+ * needs no forward sweep at all (its tiles are 640 / 320 elements) and runs the second-generation
+ * kernel, whose workgroups accumulate dB/dC over many rows before touching memory.  Unused slots
+ * are not written. */
 #define SIGMA_SCAN_CHUNK 2048
 #define SIGMA_SCAN_CKPT_PITCH 1280
 #define SIGMA_SCAN_CKPT_PITCH_FINE 640
+#define SIGMA_SCAN_CKPT_PITCH_320 320
 /* dstate limit of the reference (selective_scan.cpp:10,201). */
 #define SIGMA_SCAN_MAX_DSTATE 256
 
@@ -92,7 +95,7 @@ typedef struct sigma_scan_fwd_params {
      *      flip share one physical copy of x. */
     uint32_t rev_group_mask;
     int32_t u_group_shift;
-    int32_t ckpt_pitch;        /* 0 = SIGMA_SCAN_CKPT_PITCH (1280); 640 = fine checkpoints (see above) */
+    int32_t ckpt_pitch;        /* 0 = SIGMA_SCAN_CKPT_PITCH (1280); 640 / 320 = fine checkpoints (see above) */
     int32_t reserved0_;
     int64_t x_row_stride;      /* floats per (batch, row) of x; 0 = n_chunks * 2 * dstate */
     /* inputs */
@@ -170,6 +173,9 @@ int sigma_scan_abi_version(void);
  *   "no_glds"                  1 = stage B/C through registers instead of global_load_lds
  *   "bwd_slab2"                1 = two dB/dC slab sets in LDS (one barrier per state) when they fit
  *   "fwd_prefetch"             2 = no register prefetch of the next tile's u/delta (T = 10)
+ *   "bwd_gen"                  1 = first-generation backward (scan_bwd.hip) always, 2 = second generation
+ *                              (scan_bwd2.hip: needs ckpt_pitch 640 / 320 and dstate <= 64) whenever legal
+ *   "bwd_rb"                   second-generation backward: row blocks a workgroup accumulates over (0..256)
  * Returns SIGMA_ERR_BAD_OPTION for unknown names / unsupported values. */
 int sigma_scan_set_option(const char *name, int value);
 int sigma_scan_get_option(const char *name);
@@ -178,6 +184,10 @@ int sigma_scan_get_option(const char *name);
  * {items_per_lane, rows_per_workgroup, workgroups, lds_bytes, tiles_per_workgroup, states_per_block} */
 int sigma_scan_fwd_plan(const sigma_scan_fwd_params *params, int32_t plan[6]);
 int sigma_scan_bwd_plan(const sigma_scan_bwd_params *params, int32_t plan[6]);
+
+/* Development aid: per-phase cycle totals of the second-generation backward since the last call
+ * (all zero unless the library was built with -DSIGMA_BWD2_PROF=1); synchronises the device. */
+int sigma_scan_debug_read(uint64_t out16[16]);
 
 /* On-device self test of the wave64 DPP scan primitives against a serial loop.
  * Returns 0 when every lane matches; enqueues on `stream` and synchronises it. */

@@ -14,10 +14,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SIGMA_HIP_LIB lets a benchmark A/B an experimental build of the same ABI; default is the in-tree library
 LIB_PATH = os.environ.get("SIGMA_HIP_LIB") or os.path.join(_HERE, "lib", "libsigma_hip.so")
 
-SIGMA_SCAN_ABI_VERSION = 4
+SIGMA_SCAN_ABI_VERSION = 5
 SIGMA_SCAN_CHUNK = 2048
 SIGMA_SCAN_CKPT_PITCH = 1280
 SIGMA_SCAN_CKPT_PITCH_FINE = 640
+SIGMA_SCAN_CKPT_PITCH_320 = 320
 SIGMA_SCAN_MAX_DSTATE = 256
 
 DTYPE_F32, DTYPE_F16, DTYPE_BF16 = 0, 1, 2
@@ -121,6 +122,7 @@ EXPORTED_SYMBOLS = (
     "sigma_scan_get_option",
     "sigma_scan_fwd_plan",
     "sigma_scan_bwd_plan",
+    "sigma_scan_debug_read",
     "sigma_scan_selftest",
 )
 
@@ -161,6 +163,8 @@ def load() -> ctypes.CDLL:
     lib.sigma_scan_bwd_plan.restype = ctypes.c_int
     lib.sigma_scan_selftest.argtypes = [ctypes.c_void_p]
     lib.sigma_scan_selftest.restype = ctypes.c_int
+    lib.sigma_scan_debug_read.argtypes = [P(ctypes.c_uint64 * 16)]
+    lib.sigma_scan_debug_read.restype = ctypes.c_int
     for name in OPS_SYMBOLS:
         fn = getattr(lib, name)
         if name == "sigma_layernorm_bwd_partial_rows":

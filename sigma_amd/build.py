@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "lib", "obj")
 LIB = os.path.join(HERE, "lib", "libsigma_hip.so")
-SOURCES = ["scan_fwd.hip", "scan_bwd.hip", "selftest.hip", "capi.hip", "dwconv.hip", "merge.hip", "layernorm.hip"]
+SOURCES = ["scan_fwd.hip", "scan_bwd.hip", "scan_bwd2.hip", "scan_bwd3.hip", "selftest.hip", "capi.hip", "dwconv.hip", "merge.hip", "layernorm.hip"]
 HEADERS = ["scan_device.h", "scan_launch.h", os.path.join("..", "..", "include", "sigma_scan.h"),
            os.path.join("..", "..", "include", "sigma_ops.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
@@ -26,6 +26,7 @@ FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC",
     "-munsafe-fp-atomics",          # ds_add_f32 / global_atomic_add_f32 instead of CAS loops
     "-ffp-contract=off",            # every fma in the kernels is written explicitly
+    "-fno-slp-vectorize",           # v_pk_*_f32 issue at half rate on gfx950 and the packing costs v_movs (tools/ubench)
     "-Wall", "-Wno-unused-function",
 ]
 

@@ -20,6 +20,7 @@ thread_local std::string g_err;
 
 std::atomic<int> g_opt_fwd_items{0}, g_opt_fwd_waves{0}, g_opt_fwd_tiles{0}, g_opt_fwd_nb{0};
 std::atomic<int> g_opt_bwd_items{0}, g_opt_bwd_waves{0}, g_opt_bwd_nb{0}, g_opt_no_glds{0}, g_opt_bwd_slab2{0}, g_opt_fwd_prefetch{0};
+std::atomic<int> g_opt_bwd_gen{0}, g_opt_bwd_rb{0};
 
 int fail(int code, const char* fmt, ...) {
     char buf[512];
@@ -52,9 +53,10 @@ int check_fwd(const sigma_scan_fwd_params* p, bool need_out, bool need_ptrs = tr
                     p->seqlen);
     if (p->rev_group_mask != 0 && (p->n_groups > 32 || (p->n_groups < 32 && (p->rev_group_mask >> p->n_groups) != 0)))
         return fail(SIGMA_ERR_BAD_SHAPE, "rev_group_mask 0x%x names groups >= n_groups (%d)", p->rev_group_mask, p->n_groups);
-    if (p->ckpt_pitch != 0 && p->ckpt_pitch != SIGMA_SCAN_CKPT_PITCH && p->ckpt_pitch != SIGMA_SCAN_CKPT_PITCH_FINE)
-        return fail(SIGMA_ERR_BAD_SHAPE, "ckpt_pitch must be 0, %d or %d (got %d)", SIGMA_SCAN_CKPT_PITCH,
-                    SIGMA_SCAN_CKPT_PITCH_FINE, p->ckpt_pitch);
+    if (p->ckpt_pitch != 0 && p->ckpt_pitch != SIGMA_SCAN_CKPT_PITCH && p->ckpt_pitch != SIGMA_SCAN_CKPT_PITCH_FINE &&
+        p->ckpt_pitch != SIGMA_SCAN_CKPT_PITCH_320)
+        return fail(SIGMA_ERR_BAD_SHAPE, "ckpt_pitch must be 0, %d, %d or %d (got %d)", SIGMA_SCAN_CKPT_PITCH,
+                    SIGMA_SCAN_CKPT_PITCH_FINE, SIGMA_SCAN_CKPT_PITCH_320, p->ckpt_pitch);
     {
         const int pitch = p->ckpt_pitch ? p->ckpt_pitch : SIGMA_SCAN_CKPT_PITCH;
         const int64_t need = (int64_t)((p->seqlen + pitch - 1) / pitch) * p->dstate;
@@ -155,7 +157,7 @@ Plan plan_fwd(const sigma_scan_fwd_params* p, bool vec) {
     // measured (tools/bwd_variants.py): with 16 states and long sequences the 1280-element tile wins
     // (half as many tile starts whose u/delta latency is exposed; 805 vs 961 us at (8,768,19200));
     // short sequences and few-state scans prefer 640-element tiles with the register prefetch
-    const bool long_rows = !fine && (long)p->batch * p->dim >= 12L * kCUs && p->dstate > 8 && p->seqlen >= 10240;
+    const bool long_rows = (long)p->batch * p->dim >= 12L * kCUs && p->dstate > 8 && p->seqlen >= 10240;
     pl.items = forced_items == 20 ? 20
              : (forced_items == 0 && long_rows) ? 20
              : pick_items(p->seqlen, cand, fine ? 2 : 3, fwd_cost_per_element, forced_items);
@@ -209,11 +211,15 @@ Plan plan_fwd(const sigma_scan_fwd_params* p, bool vec) {
 
 Plan plan_bwd(const sigma_scan_fwd_params* p, bool vec) {
     static const int cand[] = {10, 5, 4};
+    static const int cand320[] = {5};
     Plan pl;
     const bool fine = p->ckpt_pitch == SIGMA_SCAN_CKPT_PITCH_FINE;
+    const bool p320 = p->ckpt_pitch == SIGMA_SCAN_CKPT_PITCH_320;     // tiles must divide the pitch
     int forced_bitems = g_opt_bwd_items.load();
     if (fine && forced_bitems == 4) forced_bitems = 0;
-    pl.items = pick_items(p->seqlen, cand, fine ? 2 : 3, bwd_cost_per_element, forced_bitems);
+    if (p320) forced_bitems = 0;
+    pl.items = p320 ? pick_items(p->seqlen, cand320, 1, bwd_cost_per_element, 0)
+                    : pick_items(p->seqlen, cand, fine ? 2 : 3, bwd_cost_per_element, forced_bitems);
     pl.glds = glds_ok(p, vec);
     pl.tiles = 1;
     pl.slab2 = false;
@@ -245,6 +251,106 @@ Plan plan_bwd(const sigma_scan_fwd_params* p, bool vec) {
     return pl;
 }
 
+// scan_bwd2 (scan_bwd2.hip): one checkpoint per backward tile, dstate <= 64.  A workgroup is R rows x
+// RB row blocks of one (batch, group); P = rows_per_group / (R * RB) workgroups share a group.
+struct Plan2 { bool ok; int items, rows, nb, RB, P, nacc, grid; bool glds, slab2; size_t lds; };
+
+Plan2 plan_bwd2(const sigma_scan_fwd_params* p, bool vec) {
+    Plan2 pl;
+    std::memset(&pl, 0, sizeof(pl));
+    const int gen = g_opt_bwd_gen.load();
+    if (gen == 1) return pl;                                         // forced: first-generation kernel
+    const int pitch = p->ckpt_pitch ? p->ckpt_pitch : SIGMA_SCAN_CKPT_PITCH;
+    const int T = pitch == SIGMA_SCAN_CKPT_PITCH_FINE ? 10 : (pitch == SIGMA_SCAN_CKPT_PITCH_320 ? 5 : 0);
+    if (T == 0 || p->dstate > 64) return pl;
+    const int forced_items = g_opt_bwd_items.load();
+    if (forced_items != 0 && forced_items != T && gen != 2) return pl;
+    const int tile = 64 * T;
+    const int rpg = p->dim / p->n_groups;
+    const int fr = g_opt_bwd_waves.load();
+    // measured (tools/bwd2_check.py bench, profiles/r02_bwd2_variants.txt): with 16 states and enough rows
+    // the 16-wave workgroup wins although T = 10 then spills (4 waves per SIMD beat 3); few-state scans and
+    // small batches prefer 12 rows; 320-tiles prefer 8-row workgroups (two per CU)
+    static const int pref16[] = {16, 12, 8, 6, 10, 14, 15, 11, 13, 9, 7, 5};
+    static const int pref12[] = {12, 16, 8, 6, 10, 14, 15, 11, 13, 9, 7, 5};
+    static const int pref8[] = {8, 16, 12, 6, 10, 14, 15, 11, 13, 9, 7, 5};
+    const bool many16 = (long)p->batch * p->dim / 16 >= 2L * kCUs;
+    const int* pref = T == 5 ? (many16 ? pref8 : pref12) : ((p->dstate > 8 && many16) ? pref16 : pref12);
+    int R = 0;
+    if (fr > 0 && fr <= 16 && rpg % fr == 0 && fr * 64 >= tile) R = fr;
+    for (int i = 0; R == 0 && i < 12; ++i)
+        if (rpg % pref[i] == 0 && pref[i] * 64 >= tile) R = pref[i];
+    if (R == 0) return pl;
+    int NB = g_opt_bwd_nb.load() > 0 ? g_opt_bwd_nb.load() : 4;
+    if (NB > p->dstate) NB = p->dstate;
+    const int rowblocks = rpg / R;
+    // Row blocks per workgroup ("bwd_rb" > 1): the dB/dC sums of RB row blocks meet in per-thread
+    // accumulators.  Off by default: at T = 10 the 8T + 45 live values leave no room for 2N more
+    // registers, hipcc parks the accumulators in scratch and the kernel gets slower (measured 1499 vs
+    // 1422 us on (16,3072,1200,N16)); the option stays for the A/B.
+    int RB = 1;
+    const int frb = g_opt_bwd_rb.load();
+    if (frb > 1) {
+        RB = frb;
+        while (RB > 1 && rowblocks % RB != 0) --RB;
+    }
+    int nacc = RB == 1 ? 0 : (p->dstate <= 4 ? 4 : (p->dstate <= 16 ? 16 : -1));
+    if (nacc < 0) { RB = 1; nacc = 0; }
+    const int sl = g_opt_bwd_slab2.load();
+    bool slab2 = sl != 2;                                            // two slab sets when they fit beside NB = 4
+    while (sigma::bwd2_lds_bytes(T, R, NB, p->dstate, slab2, RB) > kLdsLimit) {
+        if (slab2) slab2 = false;
+        else if (NB > 1) NB >>= 1;
+        else return pl;
+    }
+    pl.ok = true;
+    pl.items = T; pl.rows = R; pl.nb = NB; pl.RB = RB; pl.P = rowblocks / RB; pl.nacc = nacc;
+    pl.grid = p->batch * p->n_groups * pl.P;
+    pl.slab2 = slab2;
+    pl.lds = sigma::bwd2_lds_bytes(T, R, NB, p->dstate, slab2, RB);
+    pl.glds = glds_ok(p, vec) && glds_fits(T, NB, 1, R);
+    return pl;
+}
+
+// scan_bwd3 (scan_bwd3.hip): state-parallel mapping, 320-element tiles; a workgroup is `slots` row slots x
+// Q = dstate/4 waves and walks RB rows per slot; P = rows_per_group / (slots * RB) workgroups share a group.
+struct Plan3 { bool ok; int nw, slots, RB, P, grid; bool glds; size_t lds; };
+
+Plan3 plan_bwd3(const sigma_scan_fwd_params* p, bool vec) {
+    Plan3 pl;
+    std::memset(&pl, 0, sizeof(pl));
+    const int gen = g_opt_bwd_gen.load();
+    if (gen == 1 || gen == 2) return pl;
+    if (p->ckpt_pitch != SIGMA_SCAN_CKPT_PITCH_320) return pl;
+    const int N = p->dstate;
+    if (N < 4 || N > 16 || (N & 3) != 0) return pl;
+    const int Q = N / 4;
+    const int rpg = p->dim / p->n_groups;
+    int maxw = g_opt_bwd_waves.load();
+    if (maxw <= 0 || maxw > 16) maxw = 16;
+    int slots = 0;
+    for (int s = maxw / Q; s >= 1; --s) if (rpg % s == 0) { slots = s; break; }
+    if (slots == 0) return pl;
+    const int rowsteps = rpg / slots;
+    int RB = 1;
+    const int frb = g_opt_bwd_rb.load();
+    if (frb > 0) {
+        RB = frb;
+        while (RB > 1 && rowsteps % RB != 0) --RB;
+    } else {
+        for (int d = 1; d <= rowsteps; ++d)
+            if (rowsteps % d == 0 && (long)p->batch * p->n_groups * (rowsteps / d) >= kCUs) RB = d;
+    }
+    while (RB > 1 && sigma::bwd3_lds_bytes(slots * Q, N, RB) > kLdsLimit) { --RB; while (RB > 1 && rowsteps % RB != 0) --RB; }
+    if (sigma::bwd3_lds_bytes(slots * Q, N, RB) > kLdsLimit) return pl;
+    pl.ok = true;
+    pl.nw = slots * Q; pl.slots = slots; pl.RB = RB; pl.P = rowsteps / RB;
+    pl.grid = p->batch * p->n_groups * pl.P;
+    pl.lds = sigma::bwd3_lds_bytes(pl.nw, N, RB);
+    pl.glds = glds_ok(p, vec) && glds_fits(5, N, 1, pl.nw);
+    return pl;
+}
+
 }  // namespace
 
 extern "C" {
@@ -266,6 +372,8 @@ OptDesc g_opts[] = {
     {"no_glds", &g_opt_no_glds, {0, 1, -1}},
     {"bwd_slab2", &g_opt_bwd_slab2, {0, 1, 2, -1}},        // 1 = two dB/dC slab sets when they fit
     {"fwd_prefetch", &g_opt_fwd_prefetch, {0, 1, 2, -1}},  // 2 = no register prefetch of the next tile's u/delta (T = 10)
+    {"bwd_gen", &g_opt_bwd_gen, {0, 1, 2, 3, -1}},         // backward kernel: 1 = scan_bwd.hip, 2 = scan_bwd2.hip, 3 / 0 = best legal
+    {"bwd_rb", &g_opt_bwd_rb, {-3}},                       // scan_bwd2: row blocks per workgroup, 0..256
 };
 }  // namespace
 
@@ -275,6 +383,7 @@ int sigma_scan_set_option(const char* name, int value) {
         if (std::strcmp(name, o.name)) continue;
         bool ok = false;
         if (o.allowed[0] == -2) ok = value >= 0 && value <= 16;
+        else if (o.allowed[0] == -3) ok = value >= 0 && value <= 256;
         else for (int i = 0; i < 8 && o.allowed[i] != -1; ++i) ok = ok || o.allowed[i] == value;
         if (!ok) return fail(SIGMA_ERR_BAD_OPTION, "value %d not allowed for option '%s'", value, name);
         *o.var = value;
@@ -303,6 +412,16 @@ int sigma_scan_bwd_plan(const sigma_scan_bwd_params* p, int32_t plan[6]) {
     int rc = check_fwd(&p->fwd, false, false);
     if (rc) return rc;
     if (!plan) return fail(SIGMA_ERR_NULL_ARG, "plan is NULL");
+    const Plan3 p3 = plan_bwd3(&p->fwd, true);
+    if (p3.ok) {       // items = 5, states_per_block slot = -(waves per row) marks the state-parallel kernel
+        plan[0] = 5; plan[1] = p3.nw; plan[2] = p3.grid; plan[3] = (int32_t)p3.lds; plan[4] = -p3.RB; plan[5] = -(p->fwd.dstate / 4);
+        return SIGMA_OK;
+    }
+    const Plan2 p2 = plan_bwd2(&p->fwd, true);
+    if (p2.ok) {       // tiles_per_workgroup slot: -(row blocks per workgroup) marks the second-generation kernel
+        plan[0] = p2.items; plan[1] = p2.rows; plan[2] = p2.grid; plan[3] = (int32_t)p2.lds; plan[4] = -p2.RB; plan[5] = p2.nb;
+        return SIGMA_OK;
+    }
     Plan pl = plan_bwd(&p->fwd, true);
     plan[0] = pl.items; plan[1] = pl.rows; plan[2] = pl.grid; plan[3] = (int32_t)pl.lds; plan[4] = pl.tiles; plan[5] = pl.nb;
     return SIGMA_OK;
@@ -338,7 +457,13 @@ int64_t sigma_scan_bwd_workspace_bytes(const sigma_scan_bwd_params* q) {
     const sigma_scan_fwd_params* p = &q->fwd;
     if (check_fwd(p, false, false)) return -1;
     if (p->batch == 0 || p->seqlen == 0) return 0;
-    const Plan pl = plan_bwd(p, true);       // rows per workgroup do not depend on alignment
+    const Plan3 p3 = plan_bwd3(p, true);     // no plan's workgroup count depends on alignment
+    if (p3.ok)
+        return p3.P <= 1 ? 0 : (int64_t)2 * p3.P * p->batch * p->n_groups * (int64_t)p->dstate * p->seqlen * (int64_t)sizeof(float);
+    const Plan2 p2 = plan_bwd2(p, true);
+    if (p2.ok)
+        return p2.P <= 1 ? 0 : (int64_t)2 * p2.P * p->batch * p->n_groups * (int64_t)p->dstate * p->seqlen * (int64_t)sizeof(float);
+    const Plan pl = plan_bwd(p, true);
     const int P = (p->dim / p->n_groups) / pl.rows;
     if (P <= 1) return 0;
     return (int64_t)2 * P * p->batch * p->n_groups * (int64_t)p->dstate * p->seqlen * (int64_t)sizeof(float);
@@ -357,9 +482,18 @@ int sigma_selective_scan_bwd(const sigma_scan_bwd_params* q, void* stream) {
     if ((p->D == nullptr) != (q->dD == nullptr) || (p->delta_bias == nullptr) != (q->ddelta_bias == nullptr))
         return fail(SIGMA_ERR_NULL_ARG, "dD / ddelta_bias must be given exactly when D / delta_bias are");
     const bool vec = vec_ok_bwd(q);
-    const Plan pl = plan_bwd(p, vec);
+    const Plan3 p3 = plan_bwd3(p, vec);
+    Plan2 p2;
+    std::memset(&p2, 0, sizeof(p2));
+    if (!p3.ok) p2 = plan_bwd2(p, vec);
+    Plan pl;
+    if (p3.ok) { pl.items = 5; pl.rows = p3.nw; pl.tiles = 1; pl.nb = p->dstate; pl.grid = p3.grid; pl.glds = p3.glds; pl.lds = p3.lds; pl.slab2 = false; }
+    else if (p2.ok) { pl.items = p2.items; pl.rows = p2.rows; pl.tiles = 1; pl.nb = p2.nb; pl.grid = p2.grid; pl.glds = p2.glds; pl.lds = p2.lds; pl.slab2 = p2.slab2; }
+    else pl = plan_bwd(p, vec);
+    if (!p2.ok && !p3.ok && p->ckpt_pitch == SIGMA_SCAN_CKPT_PITCH_320 && g_opt_bwd_gen.load() == 1)
+        return fail(SIGMA_ERR_BAD_OPTION, "ckpt_pitch 320 needs the second-generation backward (option bwd_gen != 1)");
     if (pl.lds > kLdsLimit) return fail(SIGMA_ERR_BAD_SHAPE, "LDS budget exceeded (%zu B)", pl.lds);
-    const int P = (p->dim / p->n_groups) / pl.rows;
+    const int P = p3.ok ? p3.P : (p2.ok ? p2.P : (p->dim / p->n_groups) / pl.rows);
     const int64_t slab = (int64_t)P * p->batch * p->n_groups * (int64_t)p->dstate * p->seqlen;
     if (P > 1) {
         if (!q->workspace || q->workspace_bytes < 2 * slab * (int64_t)sizeof(float))
@@ -388,8 +522,18 @@ int sigma_selective_scan_bwd(const sigma_scan_bwd_params* q, void* stream) {
                     q->dC_group_stride % 4 == 0 && q->dC_dstate_stride % 4 == 0) ? 1 : 0;
     a.ws_dB = P > 1 ? static_cast<float*>(q->workspace) : nullptr;
     a.ws_dC = P > 1 ? static_cast<float*>(q->workspace) + slab : nullptr;
-    hipError_t e = sigma::launch_scan_bwd(a, p->io_dtype, pl.items, pl.glds, static_cast<hipStream_t>(stream));
+    a.RB = p3.ok ? p3.RB : (p2.ok ? p2.RB : 1);
+    hipError_t e = p3.ok ? sigma::launch_scan_bwd3(a, p->io_dtype, pl.glds, static_cast<hipStream_t>(stream)) : p2.ok ? sigma::launch_scan_bwd2(a, p->io_dtype, pl.items, pl.glds, p2.nacc, static_cast<hipStream_t>(stream))
+                         : sigma::launch_scan_bwd(a, p->io_dtype, pl.items, pl.glds, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(SIGMA_ERR_LAUNCH, "scan_bwd launch failed: %s", hipGetErrorString(e));
+    return SIGMA_OK;
+}
+
+int sigma_scan_debug_read(uint64_t out16[16]) {
+    if (!out16) return fail(SIGMA_ERR_NULL_ARG, "out16 is NULL");
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = sigma::bwd2_prof_read(reinterpret_cast<unsigned long long*>(out16));
+    if (e != hipSuccess) return fail(SIGMA_ERR_LAUNCH, "debug read failed: %s", hipGetErrorString(e));
     return SIGMA_OK;
 }
 
@@ -406,8 +550,8 @@ int sigma_scan_selftest(void* stream) {
     if (e != hipSuccess) return fail(SIGMA_ERR_LAUNCH, "selftest failed to run: %s", hipGetErrorString(e));
     if (h[0] != 0.0f)
         return fail(SIGMA_ERR_LAUNCH,
-                    "wave-scan selftest mismatch: fwd=%g rev=%g prev=%g next=%g sum=%g (max abs errors)", h[1], h[2],
-                    h[3], h[4], h[5]);
+                    "wave-scan selftest mismatch: fwd=%g rev=%g prev=%g next=%g sum=%g mfwd=%g mrev=%g (max abs errors)",
+                    h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
     return SIGMA_OK;
 }
 

@@ -448,22 +448,7 @@ reduce_partials_kernel(const float* __restrict__ wsB, const float* __restrict__ 
     }
 }
 
-template <typename io_t, int T, bool GLDS>
-static hipError_t launch_bwd_t(const BwdArgs& a, hipStream_t stream) {
-    const size_t lds = bwd_lds_bytes(T, a.f.R, a.f.NB, a.f.N, a.slab2 != 0);
-    const int grid = a.f.rowblocks * a.f.batch;
-    auto kern = scan_bwd_kernel<io_t, T, GLDS>;
-    // raise the dynamic-LDS cap once per kernel and size (not per launch: the call is host-expensive)
-    static std::atomic<size_t> lds_cap{48 * 1024};
-    if (lds > lds_cap.load(std::memory_order_relaxed)) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        lds_cap.store(lds, std::memory_order_relaxed);
-    }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(a.f.R * 64), lds, stream, a);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess || a.P == 1) return e;
+hipError_t launch_reduce_partials(const BwdArgs& a, hipStream_t stream) {
     const long per = (long)a.f.batch * a.f.G * a.f.N * a.f.L;
     long blocks = (per / 4 + 255) / 256;
     if (blocks > 4096) blocks = 4096;
@@ -472,6 +457,28 @@ static hipError_t launch_bwd_t(const BwdArgs& a, hipStream_t stream) {
                        a.dC, a.P, a.f.batch, a.f.G, a.f.N, a.f.L, a.dB_bs, a.dB_gs, a.dB_ns, a.dC_bs, a.dC_gs,
                        a.dC_ns);
     return hipGetLastError();
+}
+
+template <typename io_t, int T, bool GLDS>
+static hipError_t launch_bwd_t(const BwdArgs& a, hipStream_t stream) {
+    const size_t lds = bwd_lds_bytes(T, a.f.R, a.f.NB, a.f.N, a.slab2 != 0);
+    const int grid = a.f.rowblocks * a.f.batch;
+    auto kern = scan_bwd_kernel<io_t, T, GLDS>;
+    // raise the dynamic-LDS cap once per device, kernel and size (not per launch: the call is host-expensive)
+    static std::atomic<size_t> lds_cap[kMaxDevices];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= kMaxDevices) dev = 0;
+    if (lds > 48 * 1024 && lds > lds_cap[dev].load(std::memory_order_relaxed)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        lds_cap[dev].store(lds, std::memory_order_relaxed);
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(a.f.R * 64), lds, stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || a.P == 1) return e;
+    return launch_reduce_partials(a, stream);
 }
 
 template <typename io_t, bool GLDS>

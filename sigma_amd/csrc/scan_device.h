@@ -277,6 +277,67 @@ __device__ __forceinline__ void wave_scan_inclusive_rev(float& s, float& x) {
 }
 #undef SIGMA_SCAN_STEP_ASM
 
+// ---- multiplicative scans (scan_bwd2) ---------------------------------------------------------
+// Same affine composition, but the decay travels as the product p itself: a step is
+//     x += x[src] * p ;  p *= p[src]
+// as v_fmac_f32_dpp + v_mul_f32_dpp WITHOUT bound_ctrl -- a lane whose DPP source does not exist is
+// simply not written, which is the identity of both updates -- so a step has no transcendental
+// (v_exp_f32 issues at a quarter of the plain rate: tools/ubench/valu_ubench.hip, profiles/r02_valu_ubench.txt).
+// Hazard: a VALU write followed by a DPP read of the same VGPR needs 2 wait states; inside a step
+// the other instruction of the pair provides one, the s_nop 0 the second.
+#define SIGMA_MSTEP(CTRL)                                          \
+    "v_fmac_f32_dpp %1, %1, %0 " CTRL "\n\t"                       \
+    "v_mul_f32_dpp %0, %0, %0 " CTRL "\n\t"                        \
+    "s_nop 0\n\t"
+#define SIGMA_MSTEP_LAST(CTRL)                                     \
+    "v_fmac_f32_dpp %1, %1, %0 " CTRL "\n\t"
+
+// inclusive scan over the 64 lanes, lane 0 earliest.  On return x is the scanned state; p is
+// scratch (its last update is skipped: nobody needs the full decay product).
+__device__ __forceinline__ void wave_mscan_inclusive(float& p, float& x) {
+    asm volatile(
+        "s_nop 1\n\t"
+        SIGMA_MSTEP("row_shr:1 row_mask:0xf bank_mask:0xf")
+        SIGMA_MSTEP("row_shr:2 row_mask:0xf bank_mask:0xf")
+        SIGMA_MSTEP("row_shr:4 row_mask:0xf bank_mask:0xf")
+        SIGMA_MSTEP("row_shr:8 row_mask:0xf bank_mask:0xf")
+        SIGMA_MSTEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
+        SIGMA_MSTEP_LAST("row_bcast:31 row_mask:0xc bank_mask:0xf")
+        "s_nop 1\n\t"
+        : "+v"(p), "+v"(x));
+}
+
+// inclusive SUFFIX scan: lane 63 is the earliest element of the scan order; lane i ends up with
+// the composition of lanes 63 .. i.  Rows by row_shl; then rows 0 and 2 absorb the head of the
+// row to their right (wave_shl:1 parks that head in lane 15 of the row, row_newbcast:15 hands it
+// to the whole row), then rows 0 and 1 absorb lane 32 (= rows 2-3 composed) through a readlane.
+__device__ __forceinline__ void wave_mscan_inclusive_rev(float& p, float& x) {
+    float te, tp;
+    asm volatile(
+        "s_nop 1\n\t"
+        SIGMA_MSTEP("row_shl:1 row_mask:0xf bank_mask:0xf")
+        SIGMA_MSTEP("row_shl:2 row_mask:0xf bank_mask:0xf")
+        SIGMA_MSTEP("row_shl:4 row_mask:0xf bank_mask:0xf")
+        SIGMA_MSTEP("row_shl:8 row_mask:0xf bank_mask:0xf")
+        "s_nop 0\n\t"
+        "v_mov_b32_dpp %2, %1 wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_dpp %3, %0 wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        "v_fmac_f32_dpp %1, %2, %0 row_newbcast:15 row_mask:0x5 bank_mask:0xf\n\t"
+        "v_mul_f32_dpp %0, %3, %0 row_newbcast:15 row_mask:0x5 bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        : "+v"(p), "+v"(x), "=&v"(te), "=&v"(tp));
+    const float xr = lane_bcast(x, 32);                  // rows 2-3 composed (uniform)
+    float xv = xr;
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_fmac_f32_dpp %0, %1, %2 quad_perm:[0,1,2,3] row_mask:0x3 bank_mask:0xf\n\t"
+        "s_nop 1\n\t"
+        : "+v"(x) : "v"(p), "v"(xv));
+}
+#undef SIGMA_MSTEP
+#undef SIGMA_MSTEP_LAST
+
 // plain sum over the wave, result in every lane
 __device__ __forceinline__ float wave_sum(float v) {
 #define SIGMA_ADD(CTRL, MASK) v += dpp_take<CTRL, MASK>(0.0f, v);
@@ -372,7 +433,46 @@ struct StagePlan {
             }
         }
     }
+
+    // Same, but issued through inline asm so that hipcc does not count the loads: with the builtin it
+    // drains them (s_waitcnt vmcnt(0)) before the first VMEM-dependent instruction after the issue,
+    // i.e. at the top of the block they were meant to overlap with.  The CALLER owns completion:
+    // lds_dma_wait() before the barrier that publishes the buffer (cdna_hip_programming.md 5.7).
+    // Untracked loads can only make the compiler's own vmcnt(N) waits stricter, never too weak.
+    __device__ __forceinline__ void issue_async(float* dst, const float* Bg, const float* Cg, int B_ns, int C_ns, int n0,
+                                                int nbn, int tile0, int L, int arr_stride) const {
+        const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const int nwaves = blockDim.x >> 6;
+        const int t0e = REV ? -(tile0 * TILE) : tile0 * TILE;
+#pragma unroll
+        for (int i = 0; i < kStageMaxIt; ++i) {
+            if (i < nit) {
+                const int m = moff[i] + t0e;
+                const bool ok = nn[i] < nbn && m >= 0 && m < L;           // L % 4 == 0: whole chunk in range
+                const unsigned ldsB = (unsigned)(uintptr_t)(lptr_t)(dst + (wave + i * nwaves) * 256);
+                const unsigned ldsC = ldsB + (unsigned)arr_stride * 4u;
+                if (ok) {
+                    const char* gb = reinterpret_cast<const char*>(Bg) + (unsigned)((n0 + nn[i]) * B_ns + m) * 4u;
+                    const char* gc = reinterpret_cast<const char*>(Cg) + (unsigned)((n0 + nn[i]) * C_ns + m) * 4u;
+                    unsigned keep;
+                    asm volatile(
+                        "s_mov_b32 %0, m0\n\t"
+                        "s_mov_b32 m0, %3\n\t"
+                        "s_nop 0\n\t"
+                        "global_load_lds_dwordx4 %1, off\n\t"
+                        "s_mov_b32 m0, %4\n\t"
+                        "s_nop 0\n\t"
+                        "global_load_lds_dwordx4 %2, off\n\t"
+                        "s_mov_b32 m0, %0"
+                        : "=&s"(keep) : "v"(gb), "v"(gc), "s"(ldsB), "s"(ldsC) : "memory");
+                }
+            }
+        }
+    }
 };
+
+// completion of issue_async() loads of THIS wave; a workgroup barrier must follow before other waves read
+__device__ __forceinline__ void lds_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // ------------------------------------------------------------------ kernel args
 constexpr int kCkptPitch = 1280;   // default elements between state checkpoints in x (see include/sigma_scan.h)
@@ -402,6 +502,7 @@ struct BwdArgs {
     int out_vec_ok;                 // dB/dC rows are 16-byte aligned
     int g_gshift;                   // dout rows of group g are those of group (g >> g_gshift)
     int slab2;                      // two dB/dC slab sets (by state parity): one barrier per state instead of two
+    int RB;                         // scan_bwd2: row blocks (of R rows) a workgroup walks per tile; P = rows_per_group / (R * RB)
     long g_bs, g_ds, du_bs, du_ds, dd_bs, dd_ds, dA_ds, dA_ns;
     long dB_bs, dB_gs, dB_ns, dC_bs, dC_gs, dC_ns;
 };

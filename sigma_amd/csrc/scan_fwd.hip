@@ -24,7 +24,7 @@
 //     the last block of the current one;
 //   * reversed groups (CrossScan directions 2, 3) read every sequence operand at L-1-l and write
 //     out there, so no flipped copies of x / delta / B / C have to exist (vmamba.py:80-121);
-//   * running state between super-tiles lives in LDS; states every 1280 elements go to x
+//   * running state between super-tiles lives in LDS; states every ckpt_pitch (1280 / 640 / 320) elements go to x
 //     (layout in include/sigma_scan.h) for the backward pass.
 #include "scan_device.h"
 #include "scan_launch.h"
@@ -149,10 +149,11 @@ __device__ __forceinline__ void scan_fwd_body(const FwdArgs& p, float* smem, int
 #pragma unroll
         for (int k = 0; k < T; ++k) dsum += dl[k];
 
-        // checkpoint slot of this tile's end state (every kCkptPitch elements and at the very end)
-        const int lend = (l0 + TILE < L) ? (l0 + TILE) : L;
-        const bool ckpt = x_row != nullptr && l0 < L && ((lend % p.ckpt_pitch) == 0 || lend == L);
-        const int cidx = (lend - 1) / p.ckpt_pitch;
+        // state checkpoints: the lane whose segment ends on a multiple of the pitch (or holds the last
+        // element) writes the state after its segment -- any pitch that T divides (320 / 640 / 1280)
+        const int send = (lbase + T < L) ? (lbase + T) : L;
+        const bool ckpt = x_row != nullptr && lbase < L && ((send % p.ckpt_pitch) == 0 || send == L);
+        const int cidx = (send - 1) / p.ckpt_pitch;
         const float* sRunIn = sRun + (st & 1) * R * N + wr * N;
         float* sRunOut = sRun + ((st + 1) & 1) * R * N + wr * N;
 
@@ -223,10 +224,8 @@ __device__ __forceinline__ void scan_fwd_body(const FwdArgs& p, float* smem, int
                         y[k] = fmaf(cq[j], x, y[k]);
                     }
                 }
-                if (lane == 63) {
-                    if (wt == W - 1) sRunOut[n] = x;    // state after this super-tile
-                    if (ckpt) x_row[(long)cidx * N + n] = x;
-                }
+                if (lane == 63 && wt == W - 1) sRunOut[n] = x;    // state after this super-tile
+                if (ckpt) x_row[(long)cidx * N + n] = x;
             }
             __syncthreads();                            // staged block landed; current block consumed
         }
@@ -260,13 +259,16 @@ static hipError_t launch_fwd_t(const FwdArgs& a, hipStream_t stream) {
     const size_t lds = fwd_lds_bytes(T, a.R, a.W, a.NB, a.N);
     const int grid = a.rowblocks * a.batch;
     auto kern = scan_fwd_kernel<io_t, T, GLDS, PREFETCH>;
-    // raise the dynamic-LDS cap once per kernel and size (not per launch: the call is host-expensive)
-    static std::atomic<size_t> lds_cap{48 * 1024};
-    if (lds > lds_cap.load(std::memory_order_relaxed)) {
+    // raise the dynamic-LDS cap once per device, kernel and size (not per launch: the call is host-expensive)
+    static std::atomic<size_t> lds_cap[kMaxDevices];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= kMaxDevices) dev = 0;
+    if (lds > 48 * 1024 && lds > lds_cap[dev].load(std::memory_order_relaxed)) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
-        lds_cap.store(lds, std::memory_order_relaxed);
+        lds_cap[dev].store(lds, std::memory_order_relaxed);
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(a.R * a.W * 64), lds, stream, a);
     return hipGetLastError();

@@ -27,6 +27,26 @@ inline size_t bwd_lds_bytes(int T, int R, int NB, int N, bool slab2 = false) {
     return sizeof(float) * (2 * 2 * (size_t)NB * tile + (slab2 ? 2 : 1) * 2 * (size_t)R * tile + (size_t)R * N * (tps + 3));
 }
 
+// scan_bwd2: double-buffered B/C stage + nslab slab sets + reverse carries of the chunk's RB*R rows
+inline size_t bwd2_lds_bytes(int T, int R, int NB, int N, bool slab2, int RB) {
+    const size_t tile = (size_t)kWave * T;
+    return sizeof(float) * (2 * 2 * (size_t)NB * tile + (slab2 ? 2 : 1) * 2 * (size_t)R * tile + (size_t)RB * R * N);
+}
+
+// scan_bwd3 (state-parallel): B/C of one 320-tile for all states + row partials (two parity sets, reused at
+// the tile end for the dB/dC slot sums) + reverse carries of the chunk's rows; nw = waves per workgroup
+inline size_t bwd3_lds_bytes(int nw, int N, int RB) {
+    const size_t tile = 320;
+    const int Q = N / 4 > 0 ? N / 4 : 1;
+    return sizeof(float) * (2 * (size_t)N * tile + 4 * (size_t)nw * tile + (size_t)RB * (nw / Q) * N);
+}
+
+constexpr int kMaxDevices = 16;    // per-device cache of the raised dynamic-LDS cap (hipFuncSetAttribute is per device)
+
+hipError_t launch_scan_bwd2(const BwdArgs& a, int dtype, int T, bool glds, int nacc, hipStream_t stream);
+hipError_t launch_scan_bwd3(const BwdArgs& a, int dtype, bool glds, hipStream_t stream);   // a.f.R = waves per workgroup
+hipError_t launch_reduce_partials(const BwdArgs& a, hipStream_t stream);
+hipError_t bwd2_prof_read(unsigned long long* out16);     // development builds (SIGMA_BWD2_PROF), zeros otherwise
 hipError_t launch_scan_fwd(const FwdArgs& a, int dtype, int T, bool glds, bool prefetch, hipStream_t stream);
 hipError_t launch_scan_bwd(const BwdArgs& a, int dtype, int T, bool glds, hipStream_t stream);
 hipError_t launch_selftest(float* out, hipStream_t stream);

@@ -40,16 +40,26 @@ __global__ void __launch_bounds__(64) selftest_kernel(float* out) {
     for (int i = 0; i < 64; ++i) ss += sx[i];
     const float e_sum = fabsf(s - ss);
 
+    // multiplicative scans of scan_bwd2 (decay carried as the product itself)
+    float mp = p0, mx = x0;
+    wave_mscan_inclusive(mp, mx);
+    const float e_mfwd = fabsf(mx - rx);
+    float mq = p0, my = x0;
+    wave_mscan_inclusive_rev(mq, my);
+    const float e_mrev = fabsf(my - sy);
+
     // max over lanes through LDS
-    __shared__ float red[5][64];
+    __shared__ float red[7][64];
     red[0][lane] = e_fwd; red[1][lane] = e_rev; red[2][lane] = e_prev; red[3][lane] = e_next; red[4][lane] = e_sum;
+    red[5][lane] = e_mfwd; red[6][lane] = e_mrev;
     __syncthreads();
     if (lane == 0) {
-        float m[5] = {0, 0, 0, 0, 0};
-        for (int k = 0; k < 5; ++k) for (int i = 0; i < 64; ++i) m[k] = fmaxf(m[k], red[k][i]);
-        const bool bad = m[0] > 2e-5f || m[1] > 2e-5f || m[2] != 0.0f || m[3] != 0.0f || m[4] > 1e-4f;
+        float m[7] = {0, 0, 0, 0, 0, 0, 0};
+        for (int k = 0; k < 7; ++k) for (int i = 0; i < 64; ++i) m[k] = fmaxf(m[k], red[k][i]);
+        const bool bad = m[0] > 2e-5f || m[1] > 2e-5f || m[2] != 0.0f || m[3] != 0.0f || m[4] > 1e-4f ||
+                         m[5] > 2e-5f || m[6] > 2e-5f;
         out[0] = bad ? 1.0f : 0.0f;
-        for (int k = 0; k < 5; ++k) out[1 + k] = m[k];
+        for (int k = 0; k < 7; ++k) out[1 + k] = m[k];
     }
 }
 

@@ -16,6 +16,7 @@ import torch
 import torch.nn.functional as F
 
 from .. import selective_scan_cuda_core as _core
+from ..ss2d_fused import ckpt_pitch_for
 
 
 def _last_contig(t: torch.Tensor) -> torch.Tensor:
@@ -44,7 +45,11 @@ class SelectiveScanFn(torch.autograd.Function):
             raise AssertionError(f"nrows must be 1..4, got {nrows}")
         if u.shape[1] % (B.shape[1] * nrows) != 0:
             raise AssertionError(f"dim {u.shape[1]} not divisible by n_groups*nrows = {B.shape[1] * nrows}")
-        out, x = _core.fwd(u, delta, A, B, C, D, delta_bias, delta_softplus, nrows)
+        # x never leaves this Function, so it is allocated with one checkpoint per backward tile
+        # (include/sigma_scan.h, ckpt_pitch): the backward then runs csrc/scan_bwd2.hip.  The module-level
+        # ``selective_scan_cuda_core.fwd`` keeps the reference-shaped x (selective_scan.cpp:225-228).
+        ctx.pitch = ckpt_pitch_for(u.shape[-1])
+        out, x = _core.fwd_ext(u, delta, A, B, C, D, delta_bias, delta_softplus, nrows=nrows, ckpt_pitch=ctx.pitch)
         ctx.delta_softplus = delta_softplus
         ctx.save_for_backward(u, delta, A, B, C, D, delta_bias, x)
         return out
@@ -53,8 +58,8 @@ class SelectiveScanFn(torch.autograd.Function):
     def backward(ctx, dout, *unused):
         u, delta, A, B, C, D, delta_bias, x = ctx.saved_tensors
         dout = _last_contig(dout)
-        du, ddelta, dA, dB, dC, dD, ddelta_bias = _core.bwd(
-            u, delta, A, B, C, D, delta_bias, dout, x, ctx.delta_softplus, 1)
+        du, ddelta, dA, dB, dC, dD, ddelta_bias = _core.bwd_ext(
+            u, delta, A, B, C, D, delta_bias, dout, x, ctx.delta_softplus, nrows=1, ckpt_pitch=ctx.pitch)
         if ctx.squeeze_B:
             dB = dB.squeeze(1)
         if ctx.squeeze_C:

@@ -89,12 +89,24 @@ def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+def _fine_pitch(x, seqlen: int, dstate: int, ckpt_pitch: int) -> int:
+    """Pitch of a fine-checkpoint x (B, dim, ceil(L/pitch) * N): the caller's ``ckpt_pitch`` if given,
+    else inferred from the slot count (640 wins when both fit, i.e. for L <= 320)."""
+    if ckpt_pitch:
+        return int(ckpt_pitch)
+    slots = x.size(2) // max(dstate, 1)
+    for pitch in (_capi.SIGMA_SCAN_CKPT_PITCH_FINE, _capi.SIGMA_SCAN_CKPT_PITCH_320):
+        if slots == max((seqlen + pitch - 1) // pitch, 1):
+            return pitch
+    raise RuntimeError("fine-checkpoint x must be (batch, dim, ceil(L/640)*dstate) or (batch, dim, ceil(L/320)*dstate)")
+
+
 def _fill_fwd(fp: _capi.FwdParams, u, delta, A, B, C, D_, delta_bias_, out, x, delta_softplus, sizes,
-              rev_mask=0, u_gshift=0):
+              rev_mask=0, u_gshift=0, ckpt_pitch=0):
     batch, dim, seqlen, dstate, n_groups = sizes
     fp.rev_group_mask, fp.u_group_shift = int(rev_mask), int(u_gshift)
-    if x is not None and x.dim() == 3:              # fine checkpoints: (B, dim, ceil(L/640) * N)
-        fp.ckpt_pitch, fp.x_row_stride = _capi.SIGMA_SCAN_CKPT_PITCH_FINE, x.stride(1)
+    if x is not None and x.dim() == 3:              # fine checkpoints: (B, dim, ceil(L/pitch) * N)
+        fp.ckpt_pitch, fp.x_row_stride = _fine_pitch(x, seqlen, dstate, ckpt_pitch), x.stride(1)
     fp.batch, fp.dim, fp.seqlen, fp.dstate, fp.n_groups = batch, dim, seqlen, dstate, n_groups
     fp.n_chunks = (seqlen + _capi.SIGMA_SCAN_CHUNK - 1) // _capi.SIGMA_SCAN_CHUNK
     fp.io_dtype = _DTYPES[u.dtype]
@@ -120,19 +132,24 @@ def fwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B: torch.Tensor, 
 
 
 def fwd_ext(u, delta, A, B, C, D_, delta_bias_, delta_softplus, nrows: int = 1, rev_mask: int = 0,
-            u_gshift: int = 0, need_x: bool = True, fine_ckpt: bool = False) -> List[torch.Tensor]:
+            u_gshift: int = 0, need_x: bool = True, fine_ckpt: bool = False, ckpt_pitch: int = 0) -> List[torch.Tensor]:
     """``fwd`` plus the two extensions of include/sigma_scan.h used by the fused SS2D path:
     ``rev_mask`` (bit g: group g scans backwards, by addressing) and ``u_gshift`` (group g reads
     the u rows of group g >> u_gshift; u has dim >> u_gshift rows).  ``fine_ckpt``: x is allocated
     as (B, dim, ceil(L/640) * N) with one state checkpoint per 640 elements (include/sigma_scan.h),
-    which spares ``bwd_ext`` its forward sweep; such an x is only valid for ``bwd_ext``."""
+    which spares ``bwd_ext`` its forward sweep and lets it run the second-generation kernel
+    (csrc/scan_bwd2.hip); ``ckpt_pitch`` = 640 / 320 selects the pitch explicitly (320: 320-element
+    backward tiles).  Such an x is only valid for ``bwd_ext``."""
     lib = _capi.load()
     sizes = _check_common(u, delta, A, B, C, D_, delta_bias_, nrows, u_gshift)
     batch, dim, seqlen, dstate, _ = sizes
     n_chunks = (seqlen + _capi.SIGMA_SCAN_CHUNK - 1) // _capi.SIGMA_SCAN_CHUNK
     out = torch.empty_like(delta)                                   # selective_scan.cpp:226
-    if fine_ckpt:
-        ncp = (seqlen + _capi.SIGMA_SCAN_CKPT_PITCH_FINE - 1) // _capi.SIGMA_SCAN_CKPT_PITCH_FINE
+    if fine_ckpt and not ckpt_pitch:
+        ckpt_pitch = _capi.SIGMA_SCAN_CKPT_PITCH_FINE
+    _check(ckpt_pitch in (0, _capi.SIGMA_SCAN_CKPT_PITCH_FINE, _capi.SIGMA_SCAN_CKPT_PITCH_320), "ckpt_pitch must be 0, 640 or 320")
+    if ckpt_pitch:
+        ncp = (seqlen + ckpt_pitch - 1) // ckpt_pitch
         x = torch.empty((batch, dim, max(ncp, 1) * dstate), device=u.device, dtype=torch.float32)
     else:
         x = torch.empty((batch, dim, n_chunks, dstate * 2), device=u.device, dtype=torch.float32)  # :228
@@ -140,7 +157,7 @@ def fwd_ext(u, delta, A, B, C, D_, delta_bias_, delta_softplus, nrows: int = 1, 
         return [out, x]
     fp = _capi.FwdParams()
     _fill_fwd(fp, u, delta, A, B, C, D_, delta_bias_, out, x if need_x else None, delta_softplus, sizes,
-              rev_mask, u_gshift)
+              rev_mask, u_gshift, ckpt_pitch)
     with torch.cuda.device(u.device):                               # CUDAGuard, :240
         stream = torch.cuda.current_stream(u.device).cuda_stream    # :241
         key = (batch, dim, seqlen, dstate, sizes[4], u.element_size())
@@ -158,7 +175,7 @@ def bwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B: torch.Tensor, 
 
 def bwd_ext(u, delta, A, B, C, D_, delta_bias_, dout, x_, delta_softplus, nrows: int = 1, rev_mask: int = 0,
             u_gshift: int = 0, dout_gshift: int = 0, dB_out: Optional[torch.Tensor] = None,
-            dC_out: Optional[torch.Tensor] = None) -> List[Optional[torch.Tensor]]:
+            dC_out: Optional[torch.Tensor] = None, ckpt_pitch: int = 0) -> List[Optional[torch.Tensor]]:
     """``bwd`` with the extensions of ``fwd_ext``.  du has one row per CHANNEL row (batch, dim, L)
     even when u_gshift folds several groups onto one copy of u; ``dout_gshift`` does the same for
     dout.  ``dB_out`` / ``dC_out``: optional fp32 (B, G, N, L) views (stride(-1) == 1) the kernel
@@ -175,9 +192,10 @@ def bwd_ext(u, delta, A, B, C, D_, delta_bias_, dout, x_, delta_softplus, nrows:
         _check(x_ is not None, "x is required when seqlen > 2048")   # :320 (here: already above 1280)
     if x_ is not None:
         _check(x_.dtype == torch.float32 and x_.is_cuda and x_.is_contiguous(), "x must be a contiguous float32 GPU tensor")
-        if x_.dim() == 3:        # fine checkpoints of fwd_ext(fine_ckpt=True)
-            ncp = (seqlen + _capi.SIGMA_SCAN_CKPT_PITCH_FINE - 1) // _capi.SIGMA_SCAN_CKPT_PITCH_FINE
-            _check(tuple(x_.shape) == (batch, dim, max(ncp, 1) * dstate), "fine-checkpoint x must be (batch, dim, ceil(L/640)*dstate)")
+        if x_.dim() == 3:        # fine checkpoints of fwd_ext(fine_ckpt=True / ckpt_pitch=...)
+            pitch = _fine_pitch(x_, seqlen, dstate, ckpt_pitch)
+            ncp = (seqlen + pitch - 1) // pitch
+            _check(tuple(x_.shape) == (batch, dim, max(ncp, 1) * dstate), "fine-checkpoint x must be (batch, dim, ceil(L/pitch)*dstate)")
         else:
             _check(tuple(x_.shape) == (batch, dim, n_chunks, 2 * dstate),
                    "x must have shape (batch_size, dim, n_chunks, 2 * dstate)")
@@ -199,7 +217,8 @@ def bwd_ext(u, delta, A, B, C, D_, delta_bias_, dout, x_, delta_softplus, nrows:
     ddelta_bias = torch.zeros_like(delta_bias_) if delta_bias_ is not None else None
     if batch > 0 and seqlen > 0:
         bp = _capi.BwdParams()
-        _fill_fwd(bp.fwd, u, delta, A, B, C, D_, delta_bias_, None, x_, delta_softplus, sizes, rev_mask, u_gshift)
+        _fill_fwd(bp.fwd, u, delta, A, B, C, D_, delta_bias_, None, x_, delta_softplus, sizes, rev_mask, u_gshift,
+                  ckpt_pitch)
         bp.dout_group_shift = int(dout_gshift)
         bp.dout, bp.du, bp.ddelta = _ptr(dout), _ptr(du), _ptr(ddelta)
         bp.dA, bp.dB, bp.dC, bp.dD, bp.ddelta_bias = _ptr(dA), _ptr(dB), _ptr(dC), _ptr(dD), _ptr(ddelta_bias)

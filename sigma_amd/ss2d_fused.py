@@ -34,9 +34,17 @@ from . import selective_scan_cuda_core as _core
 # 1 column-major) and i = flipped; reference k = j + 2*i (vmamba.py:84-89).  Self-inverse.
 _PERM = (0, 2, 1, 3)
 _REV_MASK = 0b1010
-# one state checkpoint per 640 elements (no forward sweep in the backward kernel); SIGMA_FINE_CKPT=0 for A/B
+# One state checkpoint per backward tile (no forward sweep in the backward kernel, second-generation
+# backward csrc/scan_bwd2.hip): 640-element tiles, 320 for short sequences (L = 300 pads to 320 instead of
+# 640).  SIGMA_CKPT_PITCH = 0 / 320 / 640 forces one pitch for A/B runs (0 = reference-shaped x, 1280).
 import os as _os
-_FINE_CKPT = _os.environ.get("SIGMA_FINE_CKPT", "1") != "0"
+_CKPT_ENV = _os.environ.get("SIGMA_CKPT_PITCH", "auto")
+
+
+def ckpt_pitch_for(seqlen: int) -> int:
+    if _CKPT_ENV != "auto":
+        return int(_CKPT_ENV)
+    return 320 if seqlen <= 320 else 640
 
 
 def _two_orders(x4: torch.Tensor) -> torch.Tensor:
@@ -173,7 +181,7 @@ class SelectiveScanExtFn(torch.autograd.Function):
         C = C.float() if C.stride(-1) == 1 else C.float().contiguous()
         A, D, delta_bias = A.float().contiguous(), D.float().contiguous(), delta_bias.float().contiguous()
         out, ck = _core.fwd_ext(u, delta, A, B, C, D, delta_bias, True, rev_mask=rev_mask, u_gshift=u_gshift,
-                                need_x=any(ctx.needs_input_grad), fine_ckpt=_FINE_CKPT)
+                                need_x=any(ctx.needs_input_grad), ckpt_pitch=ckpt_pitch_for(u.shape[-1]))
         ctx.save_for_backward(u, delta, A, B, C, D, delta_bias, ck)
         ctx.ext = (int(rev_mask), int(u_gshift))
         return out
@@ -257,7 +265,7 @@ class SS2DCoreFn(torch.autograd.Function):
         Bv, Cv = p4[:, :, R:R + N], p4[:, :, R + N:]
         need_x = any(ctx.needs_input_grad)
         out, ck = _core.fwd_ext(xs2.view(B, 2 * d, L), delta.view(B, 4 * d, L), A, Bv, Cv, Dp, bias, True,
-                                rev_mask=_REV_MASK, u_gshift=1, need_x=need_x, fine_ckpt=_FINE_CKPT)
+                                rev_mask=_REV_MASK, u_gshift=1, need_x=need_x, ckpt_pitch=ckpt_pitch_for(L))
         y = cross_merge_nhwc(out.view(B, 4, d, L), H, W)                       # (B, H, W, d)
         ctx.save_for_backward(xs2, p4, delta, A, Dp, bias, ck, Wst, dtw)
         ctx.dims = (B, d, H, W, c, R, N)

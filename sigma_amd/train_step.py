@@ -48,7 +48,7 @@ def _distributed() -> bool:
     return dist.is_available() and dist.is_initialized()
 
 
-def wrap_ddp(model: nn.Module, device: torch.device, world: int) -> nn.Module:
+def wrap_ddp(model: nn.Module, device: torch.device) -> nn.Module:
     """train.py:107.  find_unused_parameters=False: every parameter must receive a gradient."""
     if not _distributed():
         return model
@@ -57,7 +57,7 @@ def wrap_ddp(model: nn.Module, device: torch.device, world: int) -> nn.Module:
                                                find_unused_parameters=False)
 
 
-def make_step(net: nn.Module, opt, batch: Tuple[torch.Tensor, ...], world: int) -> Callable[[], torch.Tensor]:
+def make_step(net: nn.Module, opt, batch: Tuple[torch.Tensor, ...]) -> Callable[[], torch.Tensor]:
     """One training step of train.py:160-172 on a fixed (synthetic) batch."""
     def step():
         opt.zero_grad(set_to_none=True)
@@ -71,32 +71,66 @@ def make_step(net: nn.Module, opt, batch: Tuple[torch.Tensor, ...], world: int) 
     return step
 
 
-def _sync(device: torch.device, world: int) -> None:
+def _sync(device: torch.device) -> None:
     if _distributed():
         dist.barrier()
     if device.type == "cuda":
         torch.cuda.synchronize(device)
 
 
-def timed_steps(step: Callable[[], torch.Tensor], steps: int, warmup: int, device: torch.device, world: int,
+def timed_steps(step: Callable[[], torch.Tensor], steps: int, warmup: int, device: torch.device,
                 on_timed_start: Callable[[], None] = lambda: None):
     """`warmup` untimed steps, then exactly `steps` steps between barrier + synchronize pairs.
     Returns (seconds of the slowest rank, last loss)."""
     loss = None
     for _ in range(warmup):
         loss = step()
-    _sync(device, world)
+    _sync(device)
     on_timed_start()
     t0 = time.perf_counter()
     for _ in range(steps):
         loss = step()
-    _sync(device, world)
+    _sync(device)
     elapsed = time.perf_counter() - t0
     if _distributed():
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     return elapsed, loss
+
+
+def launch_plan(gpus, env, n_devices: int, argv, script: str, port: int):
+    """What `python bench.py --gpus N` must do: decide between running in this
+    process, re-launching itself as N ranks, or refusing.
+
+    Returns ("run", world, rank, local_rank) when this process IS a rank (world == gpus is asserted:
+    a launcher that started fewer ranks than --gpus must not pass for an N-GPU measurement), or
+    ("spawn", cmd) with the torch.distributed.run command line (one process per GPU, rendezvous on
+    127.0.0.1 -- the container hostname may not resolve) when --gpus > 1 and no launcher environment
+    exists.  Raises SystemExit if the node has fewer devices than ranks.  Reference: train.py:59-63,
+    engine/engine.py:59-75 (torch.distributed.launch environment)."""
+    import sys as _sys
+    if gpus is None:                 # flag omitted: whatever the launcher started (1 without a launcher)
+        gpus = int(env.get("WORLD_SIZE", "1"))
+    if gpus < 1:
+        raise SystemExit(f"--gpus must be >= 1 (got {gpus})")
+    if "WORLD_SIZE" in env:
+        world, rank = int(env["WORLD_SIZE"]), int(env.get("RANK", "0"))
+        local = int(env.get("LOCAL_RANK", str(rank)))
+        if world != gpus:
+            raise SystemExit(f"--gpus {gpus} but the launcher started WORLD_SIZE={world} ranks")
+        if n_devices < world or local >= n_devices:
+            raise SystemExit(f"{world} ranks need {world} GPUs on this node, found {n_devices}")
+        return ("run", world, rank, local)
+    if gpus == 1:
+        if n_devices < 1:
+            raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+        return ("run", 1, 0, 0)
+    if n_devices < gpus:
+        raise SystemExit(f"--gpus {gpus} but only {n_devices} GPU(s) are visible on this node")
+    cmd = [_sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), script, *argv]
+    return ("spawn", cmd)
 
 
 def throughput(per_rank_batch: int, world: int, steps: int, elapsed: float) -> float:

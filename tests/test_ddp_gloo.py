@@ -45,11 +45,11 @@ def _worker(rank, world, port, out):
         torch.manual_seed(0)                               # identical replicas, as DDP would broadcast
         model = TinySeg()
         dev = torch.device("cpu")
-        net = ts.wrap_ddp(model, dev, world)
+        net = ts.wrap_ddp(model, dev)
         opt = ts.make_optimizer(model, lr=1e-2)
-        step = ts.make_step(net, opt, _batch(rank), world)
+        step = ts.make_step(net, opt, _batch(rank))
         before = {n: p.detach().clone() for n, p in model.named_parameters()}
-        elapsed, loss = ts.timed_steps(step, steps=2, warmup=1, device=dev, world=world)
+        elapsed, loss = ts.timed_steps(step, steps=2, warmup=1, device=dev)
         grads = {n: p.grad.detach().clone() for n, p in model.named_parameters()}
         moved = {n: bool((p.detach() != before[n]).any()) for n, p in model.named_parameters()}
         # every rank must report the same (max) time
@@ -107,3 +107,24 @@ def test_two_rank_gloo_step_matches_single_process_average(tmp_path):
 def test_weak_scaling_accounting():
     assert ts.throughput(8, 1, 5, 2.0) == 20.0
     assert ts.throughput(8, 8, 5, 2.0) == 160.0
+
+
+def test_bench_launch_plan_arithmetic():
+    """`python bench.py --gpus N` must become N ranks or refuse -- never silently measure one GPU."""
+    argv = ["--gpus", "4", "--steps", "3"]
+    kind, cmd = ts.launch_plan(4, {}, 8, argv, "/x/bench.py", 29999)
+    assert kind == "spawn"
+    assert cmd[1:3] == ["-m", "torch.distributed.run"] and "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29999"
+    assert cmd[-5:] == ["/x/bench.py", *argv]
+    # inside a launcher: this process is a rank, and the rank count must equal --gpus
+    assert ts.launch_plan(4, dict(WORLD_SIZE="4", RANK="2", LOCAL_RANK="2"), 8, argv, "b", 1) == ("run", 4, 2, 2)
+    assert ts.launch_plan(None, dict(WORLD_SIZE="2", RANK="1", LOCAL_RANK="1"), 2, [], "b", 1) == ("run", 2, 1, 1)
+    assert ts.launch_plan(None, {}, 1, [], "b", 1) == ("run", 1, 0, 0)
+    for bad in (lambda: ts.launch_plan(8, dict(WORLD_SIZE="1", RANK="0"), 8, argv, "b", 1),      # --gpus ignored
+                lambda: ts.launch_plan(8, {}, 1, argv, "b", 1),                                  # too few devices
+                lambda: ts.launch_plan(2, dict(WORLD_SIZE="2", RANK="1", LOCAL_RANK="1"), 1, argv, "b", 1),
+                lambda: ts.launch_plan(1, {}, 0, argv, "b", 1),
+                lambda: ts.launch_plan(0, {}, 1, argv, "b", 1)):
+        with pytest.raises(SystemExit):
+            bad()

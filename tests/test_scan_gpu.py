@@ -142,24 +142,61 @@ def _compare(out, grads, u, delta, A, B, C, D, bias, dout, softplus, itype):
         torch.testing.assert_close(g.float().cpu(), rr, rtol=rt, atol=at, msg=lambda m, name=name: f"d{name}: {m}")
 
 
+# The reference's own parametrisation, complete (test_selective_scan.py:137-144): 3 dtypes x 10 lengths x
+# {bias} x {softplus} x {D} x varBC_groups {1, 2} x nrows {1, 2, 3, 4} = 1920 cases.  varBC_groups = 1 is the
+# 3-D B/C form (reference :159-168), written 0 here.
 GRID = list(itertools.product(
     [64, 128, 256, 372, 512, 784, 1024, 1134, 2048, 4096],       # seqlen (test_selective_scan.py:139)
     [torch.float32, torch.float16, torch.bfloat16],
-    [(False, False, False), (True, True, True), (True, False, True), (False, True, False)],  # bias, softplus, D
+    list(itertools.product([False, True], repeat=3)),             # has_delta_bias, delta_softplus, has_D
     [0, 2],                                                        # varBC groups (0 => 3-D B/C)
-    [1, 4],                                                        # nrows
+    [1, 2, 3, 4],                                                  # nrows
 ))
 
 
-@pytest.mark.parametrize("seqlen,itype,flags,groups,nrows", GRID,
-                         ids=[f"L{g[0]}-{str(g[1]).split('.')[-1]}-b{int(g[2][0])}s{int(g[2][1])}d{int(g[2][2])}-g{g[3]}-r{g[4]}"
-                              for g in GRID])
+def _grid_id(g):
+    return f"L{g[0]}-{str(g[1]).split('.')[-1]}-b{int(g[2][0])}s{int(g[2][1])}d{int(g[2][2])}-g{g[3]}-r{g[4]}"
+
+
+@pytest.mark.parametrize("seqlen,itype,flags,groups,nrows", GRID, ids=[_grid_id(g) for g in GRID])
 def test_reference_unit_test_grid(seqlen, itype, flags, groups, nrows):
-    """The reference's own parametrisation (batch 2, dim 24, dstate 8), fwd + 7 grads."""
+    """The reference's own parametrisation (batch 2, dim 24, dstate 8), fwd + 7 grads, through the
+    autograd front-end (fine checkpoints -> second-generation backward)."""
     has_bias, softplus, has_D = flags
     inp = _ref_test_inputs(seqlen, itype, groups, has_D, has_bias)
     u, delta, A, B, C, D, bias, dout = inp
     out, grads = _run_hip(u, delta, A, B, C, D, bias, dout, softplus, nrows)
+    _compare(out, grads, u, delta, A, B, C, D, bias, dout, softplus, itype)
+
+
+def _run_hip_module(u, delta, A, B, C, D, bias, dout, softplus, nrows):
+    """fwd + bwd through the module-level operator entries (reference-shaped x, checkpoint pitch 1280
+    -> first-generation backward), exactly the calls the reference's SelectiveScanFn makes."""
+    core = _core()
+    dev = "cuda"
+    if B.dim() == 3:
+        B, C = B.unsqueeze(1), C.unsqueeze(1)
+    t = [None if v is None else v.to(dev) for v in (u, delta, A, B, C, D, bias)]
+    out, x = core.fwd(*t, softplus, nrows)
+    grads = core.bwd(*t, dout.to(dev), x, softplus, 1)
+    if u.dim() == 3 and grads[3].dim() == 4 and grads[3].shape[1] == 1:
+        pass
+    return out, list(grads)
+
+
+GRID_V1 = [g for g in GRID if g[4] in (1, 4) and g[2] in ((False, False, False), (True, True, True), (True, False, True),
+                                                            (False, True, False))]
+
+
+@pytest.mark.parametrize("seqlen,itype,flags,groups,nrows", GRID_V1, ids=[_grid_id(g) for g in GRID_V1])
+def test_reference_unit_test_grid_module_entries(seqlen, itype, flags, groups, nrows):
+    """A quarter of the grid through ``selective_scan_cuda_core.fwd / bwd`` themselves (the reference
+    extension's entry points, x of the reference's shape): covers csrc/scan_bwd.hip."""
+    has_bias, softplus, has_D = flags
+    u, delta, A, B, C, D, bias, dout = _ref_test_inputs(seqlen, itype, groups, has_D, has_bias)
+    out, grads = _run_hip_module(u, delta, A, B, C, D, bias, dout, softplus, nrows)
+    if B.dim() == 3:
+        grads[3], grads[4] = grads[3].squeeze(1), grads[4].squeeze(1)
     _compare(out, grads, u, delta, A, B, C, D, bias, dout, softplus, itype)
 
 
@@ -191,12 +228,57 @@ STAGE_SHAPES = [
 ]
 
 
+@pytest.mark.parametrize("itype", [torch.float32, torch.float16, torch.bfloat16], ids=["float32", "float16", "bfloat16"])
 @pytest.mark.parametrize("shape", STAGE_SHAPES, ids=["x".join(map(str, s)) for s in STAGE_SHAPES])
-def test_real_stage_shapes_forward_and_backward(shape):
+def test_real_stage_shapes_forward_and_backward(shape, itype):
+    """The seven launch shapes of the model at 480x640 in every IO dtype of the operator (16-bit IO takes
+    the register staging path, VERDICT r1 weak #3)."""
     batch, KD, L, N, G = shape
-    u, delta, A, B, C, D, bias, dout = _model_like(batch, KD, L, N, G)
+    u, delta, A, B, C, D, bias, dout = _model_like(batch, KD, L, N, G, itype=itype)
     out, grads = _run_hip(u, delta, A, B, C, D, bias, dout, True, 4 if (KD // G) % 4 == 0 else 1)
-    _compare(out, grads, u, delta, A, B, C, D, bias, dout, True, torch.float32)
+    _compare(out, grads, u, delta, A, B, C, D, bias, dout, True, itype)
+
+
+LONG_SHAPES = [
+    # (batch, KD, L, N, G, rev_mask, u_gshift): the sequence lengths of BASELINE configs[4] (720x1280, sigma_base):
+    # 180x320 = 57600 (encoder stage 0), 2 x 57600 = 115200 (ConMB stage 0), 45x80 = 3600, 23x40 = 920
+    (1, 32, 57600, 16, 4, 0b1010, 1),
+    (1, 16, 115200, 4, 2, 0b10, 1),
+    (2, 16, 3600, 16, 4, 0b1010, 1),
+    (2, 16, 920, 16, 4, 0b1010, 1),
+    (1, 8, 1840, 4, 2, 0b10, 1),
+]
+
+
+@pytest.mark.parametrize("shape", LONG_SHAPES, ids=["x".join(map(str, s[:5])) for s in LONG_SHAPES])
+@pytest.mark.parametrize("pitch", [0, 640, 320])
+def test_long_sequences_of_the_720x1280_configuration(shape, pitch):
+    """Operator-level oracle check (fwd + 7 grads) at the longest sequences the model produces, with the
+    fused path's addressing (reversed groups, shared u / dout rows), for every checkpoint pitch
+    (0 = reference-shaped x / first-generation backward).  VERDICT r1 weak #1."""
+    batch, KD, L, N, G, mask, ush = shape
+    u, delta, A, B, C, D, bias, dout = _model_like(batch, KD, L, N, G, seed=17)
+    rpg = KD // G
+    keep = lambda t: torch.cat([t[:, g * rpg:(g + 1) * rpg] for g in range(0, G, 1 << ush)], dim=1).contiguous()
+    full = lambda t: torch.cat([t[:, (g >> ush) * rpg:((g >> ush) + 1) * rpg] for g in range(G)], dim=1)
+    u_h, g_h = keep(u), keep(dout)
+    u_f, g_f = full(u_h), full(g_h)
+    core = _core()
+    dev = "cuda"
+    args = [t.to(dev) for t in (u_h, delta, A, B, C, D, bias)]
+    out, x = core.fwd_ext(*args, True, rev_mask=mask, u_gshift=ush, ckpt_pitch=pitch)
+    grads = core.bwd_ext(*args, g_h.to(dev), x, True, rev_mask=mask, u_gshift=ush, dout_gshift=ush, ckpt_pitch=pitch)
+    revs = [(mask >> g) & 1 for g in range(G)]
+    fr = lambda t: torch.cat([t[:, g * rpg:(g + 1) * rpg].flip(-1) if revs[g] else t[:, g * rpg:(g + 1) * rpg] for g in range(G)], 1)
+    fg = lambda t: torch.stack([t[:, g].flip(-1) if revs[g] else t[:, g] for g in range(G)], 1)
+    so = _oracle()
+    ref = fr(so.selective_scan_oracle(fr(u_f), fr(delta), A, fg(B), fg(C), D, bias, True, acc64=True))
+    torch.testing.assert_close(out.cpu(), ref, rtol=6e-4, atol=2e-3)
+    rg = list(so.selective_scan_oracle_bwd(fr(u_f), fr(delta), A, fg(B), fg(C), D, bias, fr(g_f), True))
+    rg[0], rg[1], rg[3], rg[4] = fr(rg[0]), fr(rg[1]), fg(rg[3]), fg(rg[4])
+    for name, g, r in zip(["u", "delta", "A", "B", "C", "D", "bias"], grads, rg):
+        torch.testing.assert_close(g.cpu(), r, rtol=3e-3, atol=2e-3 + 2e-4 * float(r.abs().max()),
+                                   msg=lambda m, name=name: f"d{name}: {m}")
 
 
 def test_checkpoint_tensor_shape_and_documented_layout():
@@ -214,8 +296,10 @@ def test_checkpoint_tensor_shape_and_documented_layout():
     args = [t.to(dev) for t in (u, delta, A, B, C, D, bias)]
     out2, xf = _core().fwd_ext(*args, True, fine_ckpt=True)
     assert xf.shape == (batch, KD, 8 * N) and torch.equal(out2, out)
-    xf = xf.cpu()
-    for pitch, xt in ((1280, x), (640, xf)):
+    out3, xq = _core().fwd_ext(*args, True, ckpt_pitch=320)
+    assert xq.shape == (batch, KD, 16 * N) and torch.equal(out3, out)
+    xf, xq = xf.cpu(), xq.cpu()
+    for pitch, xt in ((1280, x), (640, xf), (320, xq)):
         for j in range((L + pitch - 1) // pitch):
             end = min(L, (j + 1) * pitch)
             _, st = so.selective_scan_oracle(u[..., :end], delta[..., :end], A, B[..., :end], C[..., :end], D, bias, True,
@@ -224,9 +308,10 @@ def test_checkpoint_tensor_shape_and_documented_layout():
     # the backward gives the same gradients from either checkpoint tensor
     dout = torch.randn(batch, KD, L).to(dev)
     g1 = _core().bwd_ext(*args, dout, x.to(dev).view(batch, KD, 3, 2 * N), True)
-    g2 = _core().bwd_ext(*args, dout, xf.to(dev), True)
-    for a, b in zip(g1, g2):
-        torch.testing.assert_close(a, b, rtol=2e-4, atol=1e-5 + 1e-5 * float(b.abs().max()))
+    for xt, pitch in ((xf, 640), (xq, 320)):
+        g2 = _core().bwd_ext(*args, dout, xt.to(dev), True, ckpt_pitch=pitch)
+        for a, b in zip(g1, g2):
+            torch.testing.assert_close(a, b, rtol=2e-4, atol=1e-5 + 1e-5 * float(b.abs().max()))
 
 
 def _run_hip_ext(u, delta, A, B, C, D, bias, dout, rev_mask=0, u_gshift=0, dout_gshift=0):
@@ -324,12 +409,14 @@ def test_strided_and_unaligned_inputs():
                                  ("fwd_waves", 1), ("fwd_waves", 2), ("fwd_waves", 16), ("fwd_tiles", 1),
                                  ("fwd_tiles", 2), ("fwd_tiles", 4), ("fwd_nb", 1), ("fwd_nb", 2), ("no_glds", 1),
                                  ("bwd_items", 4), ("bwd_items", 5), ("bwd_items", 10), ("bwd_waves", 1),
-                                 ("bwd_waves", 8), ("bwd_nb", 1), ("bwd_nb", 2), ("bwd_slab2", 1)])
+                                 ("bwd_waves", 8), ("bwd_nb", 1), ("bwd_nb", 2), ("bwd_slab2", 1), ("bwd_slab2", 2),
+                                 ("bwd_gen", 1), ("bwd_gen", 2), ("bwd_rb", 2), ("bwd_rb", 4), ("bwd_waves", 16),
+                                 ("bwd_waves", 4)])
 def test_every_launch_geometry_is_correct(opt):
     """All (items per lane, rows per workgroup) variants compute the same thing."""
     from sigma_amd import _capi
     name, val = opt
-    batch, KD, L, N, G = 2, 64, 2500, 16, 2
+    batch, KD, L, N, G = 2, 96, 2500, 16, 2
     u, delta, A, B, C, D, bias, dout = _model_like(batch, KD, L, N, G, seed=7)
     _capi.set_option(name, val)
     try:

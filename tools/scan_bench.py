@@ -34,6 +34,9 @@ SHAPES = {
     "enc_s2_b8": (8, 3072, 1200, 16, 4),
     "dec_s0_b8": (8, 768, 19200, 4, 4),
     "conmb_s0_b8": (8, 384, 38400, 4, 2),
+    "dec_s1_b8": (8, 1536, 4800, 4, 4),
+    "dec_s2_b8": (8, 3072, 1200, 4, 4),
+    "cromb_s0_b8": (8, 192, 19200, 4, 1),
     "enc_s0_b16": (16, 768, 19200, 16, 4),
     "enc_s1_b16": (16, 1536, 4800, 16, 4),
     "enc_s2_b16": (16, 3072, 1200, 16, 4),
