@@ -57,6 +57,9 @@ def parse():
     ap.add_argument("--conv-autotune", action="store_true", help="torch.backends.cudnn.benchmark = True (slow start)")
     ap.add_argument("--force-ddp", action="store_true",
                     help="single process: still create the RCCL process group and wrap the model in DDP (plumbing check)")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture the step (fwd + bwd + AdamW) as one HIP graph and time replays (single process); the "
+                         "roofline object then comes from a few eager steps run before the capture")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="seconds of CPU oracle work")
     ap.add_argument("--kernel-report", default="", help="write the per-kernel-shape table (json) here")
     return ap.parse_args()
@@ -204,7 +207,8 @@ def main():
     finally:
         os.chdir(cwd)
     model.to(dev).train()
-    opt = ts.make_optimizer(model)
+    use_graph = bool(a.graph) and not ddp
+    opt = ts.make_optimizer(model, capturable=use_graph)
     net = ts.wrap_ddp(model, dev)           # train.py:107
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     rgb = torch.randn(a.batch, 3, a.height, a.width, generator=g).to(dev)
@@ -215,8 +219,21 @@ def main():
     def start_timers():
         timer.enabled = True
 
-    elapsed, loss = ts.timed_steps(step, a.steps, a.warmup, dev, on_timed_start=start_timers)
-    timer.enabled = False
+    if use_graph:
+        # kernel timings (HIP events per launch) cannot live inside a captured graph: take them from two
+        # eager steps first, then capture and time replays of the identical step
+        step(); torch.cuda.synchronize()
+        timer.enabled = True
+        step(); step(); torch.cuda.synchronize()
+        timer.enabled = False
+        eager_scan_steps = 2
+        core.set_launch_hook(None)
+        gstep, _ = ts.make_graphed_step(net, opt, (rgb, mx, label))
+        elapsed, loss = ts.timed_steps(gstep, a.steps, a.warmup, dev)
+    else:
+        eager_scan_steps = a.steps
+        elapsed, loss = ts.timed_steps(step, a.steps, a.warmup, dev, on_timed_start=start_timers)
+        timer.enabled = False
 
     if rank == 0:
         table = timer.table()
@@ -235,7 +252,7 @@ def main():
                         algorithmic_bytes=int(d["algorithmic_MB"] * 1e6), kernel=d["kernel"], shape=d["shape"],
                         avg_launch_us=round(d["avg_us"], 1), launches=d["launches"],
                         share_of_scan_time=round(d["total_ms"] / scan_ms, 3),
-                        scan_share_of_step=round(scan_ms / (elapsed * 1e3), 3))
+                        scan_share_of_step=round((scan_ms / eager_scan_steps) / (elapsed / a.steps * 1e3), 3))
         roof_fwd = None
         fwd_rows = [r for r in rows if r["kernel"] == "scan_fwd"]
         if fwd_rows:
@@ -257,7 +274,7 @@ def main():
                     vs_baseline=None, dtype="f32", data="synthetic",
                     config=dict(workload=f"{a.backbone} training step (fwd+bwd+AdamW), RGB-X pairs {a.height}x{a.width}, "
                                          f"{a.classes} classes, fp32", per_gpu_batch=a.batch,
-                                global_batch=a.batch * world, parallelism=f"dp{world}",
+                                global_batch=a.batch * world, parallelism=f"dp{world}", hip_graph=use_graph,
                                 loss=round(float(loss.item()), 4)),
                     roofline=roof, roofline_fwd=roof_fwd, cpu_baseline=cpu)
         print(json.dumps(line), flush=True)

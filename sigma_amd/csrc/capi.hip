@@ -20,7 +20,7 @@ thread_local std::string g_err;
 
 std::atomic<int> g_opt_fwd_items{0}, g_opt_fwd_waves{0}, g_opt_fwd_tiles{0}, g_opt_fwd_nb{0};
 std::atomic<int> g_opt_bwd_items{0}, g_opt_bwd_waves{0}, g_opt_bwd_nb{0}, g_opt_no_glds{0}, g_opt_bwd_slab2{0}, g_opt_fwd_prefetch{0};
-std::atomic<int> g_opt_bwd_gen{0}, g_opt_bwd_rb{0};
+std::atomic<int> g_opt_bwd_gen{0}, g_opt_bwd_rb{0}, g_opt_bwd_notouch{0};
 
 int fail(int code, const char* fmt, ...) {
     char buf[512];
@@ -275,7 +275,8 @@ Plan2 plan_bwd2(const sigma_scan_fwd_params* p, bool vec) {
     static const int pref12[] = {12, 16, 8, 6, 10, 14, 15, 11, 13, 9, 7, 5};
     static const int pref8[] = {8, 16, 12, 6, 10, 14, 15, 11, 13, 9, 7, 5};
     const bool many16 = (long)p->batch * p->dim / 16 >= 2L * kCUs;
-    const int* pref = T == 5 ? (many16 ? pref8 : pref12) : ((p->dstate > 8 && many16) ? pref16 : pref12);
+    const int* pref = (p->dstate > 8 && many16) ? pref16 : pref12;
+    (void)pref8;
     int R = 0;
     if (fr > 0 && fr <= 16 && rpg % fr == 0 && fr * 64 >= tile) R = fr;
     for (int i = 0; R == 0 && i < 12; ++i)
@@ -324,10 +325,15 @@ Plan3 plan_bwd3(const sigma_scan_fwd_params* p, bool vec) {
     if (p->ckpt_pitch != SIGMA_SCAN_CKPT_PITCH_320) return pl;
     const int N = p->dstate;
     if (N < 4 || N > 16 || (N & 3) != 0) return pl;
+    // measured (profiles/r02_bwd3_variants.txt): the state-parallel mapping wins where a workgroup walks many
+    // rows per tile and a wave holds the whole row -- 4 states, short sequences (dec (8,3072,1200,N4): 243 vs
+    // 323 us) -- and loses with 16 states (1650 vs 1300 us) and on long rows; "bwd_gen" = 3 forces it
+    const bool auto_ok = N <= 4 && p->seqlen <= 1280;
+    if (gen != 3 && !auto_ok) return pl;
     const int Q = N / 4;
     const int rpg = p->dim / p->n_groups;
     int maxw = g_opt_bwd_waves.load();
-    if (maxw <= 0 || maxw > 16) maxw = 16;
+    if (maxw <= 0 || maxw > 16) maxw = 12;                            // 12 waves: 168-VGPR build, no spills
     int slots = 0;
     for (int s = maxw / Q; s >= 1; --s) if (rpg % s == 0) { slots = s; break; }
     if (slots == 0) return pl;
@@ -342,6 +348,7 @@ Plan3 plan_bwd3(const sigma_scan_fwd_params* p, bool vec) {
             if (rowsteps % d == 0 && (long)p->batch * p->n_groups * (rowsteps / d) >= kCUs) RB = d;
     }
     while (RB > 1 && sigma::bwd3_lds_bytes(slots * Q, N, RB) > kLdsLimit) { --RB; while (RB > 1 && rowsteps % RB != 0) --RB; }
+    if (gen != 3 && RB < 4) return pl;                                // too few rows per workgroup to amortise a tile
     if (sigma::bwd3_lds_bytes(slots * Q, N, RB) > kLdsLimit) return pl;
     pl.ok = true;
     pl.nw = slots * Q; pl.slots = slots; pl.RB = RB; pl.P = rowsteps / RB;
@@ -373,6 +380,7 @@ OptDesc g_opts[] = {
     {"bwd_slab2", &g_opt_bwd_slab2, {0, 1, 2, -1}},        // 1 = two dB/dC slab sets when they fit
     {"fwd_prefetch", &g_opt_fwd_prefetch, {0, 1, 2, -1}},  // 2 = no register prefetch of the next tile's u/delta (T = 10)
     {"bwd_gen", &g_opt_bwd_gen, {0, 1, 2, 3, -1}},         // backward kernel: 1 = scan_bwd.hip, 2 = scan_bwd2.hip, 3 / 0 = best legal
+    {"bwd_notouch", &g_opt_bwd_notouch, {0, 1, -1}},       // 1 = no L2 warm-up touches of the next row step
     {"bwd_rb", &g_opt_bwd_rb, {-3}},                       // scan_bwd2: row blocks per workgroup, 0..256
 };
 }  // namespace
@@ -522,6 +530,7 @@ int sigma_selective_scan_bwd(const sigma_scan_bwd_params* q, void* stream) {
                     q->dC_group_stride % 4 == 0 && q->dC_dstate_stride % 4 == 0) ? 1 : 0;
     a.ws_dB = P > 1 ? static_cast<float*>(q->workspace) : nullptr;
     a.ws_dC = P > 1 ? static_cast<float*>(q->workspace) + slab : nullptr;
+    a.flags = g_opt_bwd_notouch.load() ? 1 : 0;
     a.RB = p3.ok ? p3.RB : (p2.ok ? p2.RB : 1);
     hipError_t e = p3.ok ? sigma::launch_scan_bwd3(a, p->io_dtype, pl.glds, static_cast<hipStream_t>(stream)) : p2.ok ? sigma::launch_scan_bwd2(a, p->io_dtype, pl.items, pl.glds, p2.nacc, static_cast<hipStream_t>(stream))
                          : sigma::launch_scan_bwd(a, p->io_dtype, pl.items, pl.glds, static_cast<hipStream_t>(stream));

@@ -112,6 +112,55 @@ __device__ __forceinline__ cold_args_t cold_args() {
     return kp;
 }
 
+// L2 warm-up of the NEXT tile's u / delta / dout segments of a row (2.5 KB each at T = 10): lanes 0..nl-1 touch
+// one 128-byte line each.  Issued as LDS-DMA into a 256-byte dummy area: no VGPR destination, so nothing the
+// compiler could reuse while the load is in flight (an asm load INTO a register counts as written at once and
+// its register was re-used as the next address: memory faults).  Untracked like the B/C stream; the caller's
+// lds_dma_wait() at the end of the staging block retires them.  Turns the ~2 us HBM miss at the top of the next
+// row step into an L2 hit.
+__device__ __forceinline__ void touch_lines(const void* seg, int nbytes, int lane, unsigned lds_dummy) {
+    const char* pa = reinterpret_cast<const char*>(seg) + lane * 128;
+    if (lane * 128 < nbytes) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(pa), "s"(lds_dummy) : "memory");
+    }
+}
+
+// Sum of one float2 column over the RR row slabs, fixed order w = 0 .. RR-1.  All RR reads are issued
+// before the first add: with a run-time trip count hipcc emits read / s_waitcnt lgkmcnt(0) / add per
+// slab, i.e. RR LDS latencies back to back (~2000 cycles per state at RR = 16, profiles/r02_bwd2_phases.txt).
+template <int RR>
+__device__ __forceinline__ float2 colsum_fixed(const float* __restrict__ colp, int stride) {
+    float2 v[RR];
+#pragma unroll
+    for (int w = 0; w < RR; ++w) v[w] = *reinterpret_cast<const float2*>(colp + w * stride);
+    float2 s = make_float2(0.f, 0.f);
+#pragma unroll
+    for (int w = 0; w < RR; ++w) { s.x += v[w].x; s.y += v[w].y; }
+    return s;
+}
+
+__device__ __forceinline__ float2 colsum(const float* __restrict__ colp, int stride, int R) {
+    // batches of 8 reads in flight (16 temporaries): more would push the 128-VGPR build into spills
+    float2 s = make_float2(0.f, 0.f);
+    int w = 0;
+    for (; w + 8 <= R; w += 8) {
+        const float2 t = colsum_fixed<8>(colp + w * stride, stride);
+        s.x += t.x; s.y += t.y;
+    }
+    if (w + 4 <= R) {
+        const float2 t = colsum_fixed<4>(colp + w * stride, stride);
+        s.x += t.x; s.y += t.y;
+        w += 4;
+    }
+    for (; w < R; ++w) {
+        const float2 v = *reinterpret_cast<const float2*>(colp + w * stride);
+        s.x += v.x; s.y += v.y;
+    }
+    return s;
+}
+
 }  // namespace
 
 template <typename io_t, int T, bool GLDS, bool REV, int NACC>
@@ -247,6 +296,23 @@ __device__ __forceinline__ void scan_bwd2_body(const BwdArgs& q, float* smem, in
 #pragma unroll
             for (int k = 0; k < T; ++k) dsum += dl[k];
 
+            if (GLDS && !(q.flags & 1)) {
+                const unsigned touch_sink = (unsigned)(uintptr_t)(lptr_t)(sRv + RB * R * N);      // 64 dummy floats
+                // next step of THIS wave: same tile, next row block -- or the tile to the left of its first row
+                const int jn = (rb + 1 < RB) ? j : j - 1;
+                if (jn >= 0) {
+                    const int rn = (rb + 1 < RB) ? r + R : row_c0 + wave;
+                    const int urn = rn - ((g - (g >> kq->f.u_gshift)) * rpg);
+                    const int grn = rn - ((g - (g >> kq->g_gshift)) * rpg);
+                    const int l0n = jn * TILE;
+                    const int m0 = REV ? (L - l0n - TILE < 0 ? 0 : L - l0n - TILE) : l0n;         // first memory element
+                    const int m1 = REV ? L - l0n : (l0n + TILE < L ? l0n + TILE : L);
+                    const int nb = (m1 - m0) * (int)sizeof(io_t);
+                    touch_lines(reinterpret_cast<const io_t*>(kq->f.u) + (long)b * kq->f.u_bs + (long)urn * kq->f.u_ds + m0, nb, lane, touch_sink);
+                    touch_lines(reinterpret_cast<const io_t*>(kq->f.delta) + (long)b * kq->f.dt_bs + (long)rn * kq->f.dt_ds + m0, nb, lane, touch_sink);
+                    touch_lines(reinterpret_cast<const io_t*>(kq->dout) + (long)b * kq->g_bs + (long)grn * kq->g_ds + m0, nb, lane, touch_sink);
+                }
+            }
             PROF(1)                                            // row prologue: loads, softplus
             for (int sb = 0; sb < nsb; ++sb) {
                 const float* cur = sBC + (step & 1) * bufsz;
@@ -340,12 +406,7 @@ __device__ __forceinline__ void scan_bwd2_body(const BwdArgs& q, float* smem, in
                     if (nn == nend - 1) { if constexpr (GLDS) lds_dma_wait(); __syncthreads(); } else lds_barrier();
                     PROF(6)                                    // barrier wait
                     if (col_on) {
-                        float2 s = make_float2(0.f, 0.f);
-                        const float* colp = sRedN + col_c * TILE + col_pp;
-                        for (int w = 0; w < R; ++w) {
-                            const float2 v = *reinterpret_cast<const float2*>(colp + w * 2 * TILE);
-                            s.x += v.x; s.y += v.y;
-                        }
+                        const float2 s = colsum(sRedN + col_c * TILE + col_pp, 2 * TILE, R);
                         if constexpr (NACC > 0) {
                             acc[n].x += s.x; acc[n].y += s.y;
                         } else {

@@ -178,9 +178,6 @@ __device__ __forceinline__ void scan_bwd3_body(const BwdArgs& q, float* smem, in
 
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
-                // the four states are unrolled only for static accumulator indices: keep hipcc from hoisting the
-                // next state's LDS reads over this state's work (it would hold 4 x 2T more registers and spill)
-                __builtin_amdgcn_sched_barrier(0);
                 const float An = lane_bcast(Av, s);
                 const float A2 = An * kLog2e;
                 const float x0 = lane_bcast(X0v, s);
@@ -231,6 +228,12 @@ __device__ __forceinline__ void scan_bwd3_body(const BwdArgs& q, float* smem, in
                 }
                 rvout_v = lane_put3(e, s, rvout_v);
                 dA_v = lane_put3(wave_sum(dAp), s, dA_v);
+                // The four states are unrolled only for static accumulator indices.  Left alone, hipcc sinks the
+                // psx / psa updates of all four states below the last one and keeps dx, B and t of every state
+                // alive until then (+15 registers per state: 143 instead of 87 VGPRs).  Pinning the sums here
+                // costs no instruction.
+#pragma unroll
+                for (int k = 0; k < T; ++k) asm volatile("" : "+v"(psx[k]), "+v"(psa[k]));
             }
 
             cold_args3_t ke = cold_args3();
@@ -247,12 +250,21 @@ __device__ __forceinline__ void scan_bwd3_body(const BwdArgs& q, float* smem, in
                 lds_barrier();
                 duty = quad == (step % Q);
                 if (duty) {
+                    // all reads of the Q partials in flight before the first add (Q <= 4)
+                    const float* src0 = sPart + ((par * nw + slot * Q) * 2) * TILE + lane * T;
+                    float px[4][T], pa[4][T];
 #pragma unroll
-                    for (int k = 0; k < T; ++k) { psx[k] = 0.0f; psa[k] = 0.0f; }
-                    for (int w = 0; w < Q; ++w) {
-                        const float* src = sPart + ((par * nw + slot * Q + w) * 2) * TILE + lane * T;
+                    for (int w = 0; w < 4; ++w) {
+                        const float* src = src0 + (w < Q ? w : 0) * 2 * TILE;
 #pragma unroll
-                        for (int k = 0; k < T; ++k) { psx[k] += src[k]; psa[k] += src[TILE + k]; }
+                        for (int k = 0; k < T; ++k) { px[w][k] = src[k]; pa[w][k] = src[TILE + k]; }
+                    }
+#pragma unroll
+                    for (int k = 0; k < T; ++k) {
+                        float sx = px[0][k], sa = pa[0][k];
+#pragma unroll
+                        for (int w = 1; w < 4; ++w) { sx += (w < Q) ? px[w][k] : 0.0f; sa += (w < Q) ? pa[w][k] : 0.0f; }
+                        psx[k] = sx; psa[k] = sa;
                     }
                 }
                 par ^= 1;
@@ -308,7 +320,15 @@ __device__ __forceinline__ void scan_bwd3_body(const BwdArgs& q, float* smem, in
                 const int pp = idx - n * TILE;                // scan position inside the tile
                 const int qd = n >> 2, s = n & 3;
                 float sum = 0.0f;
-                for (int sl = 0; sl < slots; ++sl) sum += sPart[((sl * Q + qd) * 4 + s) * TILE + pp];
+                const float* colp = sPart + (qd * 4 + s) * TILE + pp;
+                const int cstride = Q * 4 * TILE;
+                int sl = 0;
+                for (; sl + 4 <= slots; sl += 4) {
+                    const float v0 = colp[sl * cstride], v1 = colp[(sl + 1) * cstride], v2 = colp[(sl + 2) * cstride],
+                                v3 = colp[(sl + 3) * cstride];
+                    sum += v0; sum += v1; sum += v2; sum += v3;
+                }
+                for (; sl < slots; ++sl) sum += colp[sl * cstride];
                 const int m = REV ? (L - 1 - l0 - pp) : (l0 + pp);
                 if (m >= 0 && m < L) obase[(long)n * o_ns + m] = sum;
             }
@@ -322,8 +342,9 @@ __device__ __forceinline__ void scan_bwd3_body(const BwdArgs& q, float* smem, in
     }
 }
 
-template <typename io_t, bool GLDS>
-__global__ void __launch_bounds__(1024)
+// MAXW = 16: 128-VGPR budget (4 waves per SIMD); MAXW = 12: 168 VGPRs (3 waves per SIMD, no spills)
+template <typename io_t, bool GLDS, int MAXW>
+__global__ void __launch_bounds__(64 * MAXW)
 scan_bwd3_kernel(const BwdArgs q) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lb = xcd_logical_block(blockIdx.x, gridDim.x);
@@ -336,12 +357,12 @@ scan_bwd3_kernel(const BwdArgs q) {
     else scan_bwd3_body<io_t, GLDS, false>(q, smem, b, g, chunk);
 }
 
-template <typename io_t, bool GLDS>
-static hipError_t launch_bwd3_t(const BwdArgs& a, hipStream_t stream) {
+template <typename io_t, bool GLDS, int MAXW>
+static hipError_t launch_bwd3_w(const BwdArgs& a, hipStream_t stream) {
     const int nw = a.f.R;                                  // waves per workgroup = slots * Q
     const size_t lds = bwd3_lds_bytes(nw, a.f.N, a.RB);
     const int grid = a.f.batch * a.f.G * a.P;
-    auto kern = scan_bwd3_kernel<io_t, GLDS>;
+    auto kern = scan_bwd3_kernel<io_t, GLDS, MAXW>;
     static std::atomic<size_t> lds_cap[kMaxDevices];
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -356,6 +377,11 @@ static hipError_t launch_bwd3_t(const BwdArgs& a, hipStream_t stream) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || a.P == 1) return e;
     return launch_reduce_partials(a, stream);
+}
+
+template <typename io_t, bool GLDS>
+static hipError_t launch_bwd3_t(const BwdArgs& a, hipStream_t stream) {
+    return a.f.R > 12 ? launch_bwd3_w<io_t, GLDS, 16>(a, stream) : launch_bwd3_w<io_t, GLDS, 12>(a, stream);
 }
 
 hipError_t launch_scan_bwd3(const BwdArgs& a, int dtype, bool glds, hipStream_t stream) {

@@ -30,7 +30,7 @@ inline size_t bwd_lds_bytes(int T, int R, int NB, int N, bool slab2 = false) {
 // scan_bwd2: double-buffered B/C stage + nslab slab sets + reverse carries of the chunk's RB*R rows
 inline size_t bwd2_lds_bytes(int T, int R, int NB, int N, bool slab2, int RB) {
     const size_t tile = (size_t)kWave * T;
-    return sizeof(float) * (2 * 2 * (size_t)NB * tile + (slab2 ? 2 : 1) * 2 * (size_t)R * tile + (size_t)RB * R * N);
+    return sizeof(float) * (2 * 2 * (size_t)NB * tile + (slab2 ? 2 : 1) * 2 * (size_t)R * tile + (size_t)RB * R * N + 64);   // + touch sink
 }
 
 // scan_bwd3 (state-parallel): B/C of one 320-tile for all states + row partials (two parity sets, reused at

@@ -42,6 +42,8 @@ class EncoderDecoder(nn.Module):
     def __init__(self, cfg=None, criterion=nn.CrossEntropyLoss(reduction="mean", ignore_index=255),
                  norm_layer=nn.BatchNorm2d):
         super().__init__()
+        from ..tuning import enable_tuned_gemms
+        enable_tuned_gemms()                                 # library GEMMs: committed solution table (sigma_amd/tuning.py)
         self.norm_layer = norm_layer
         if cfg.backbone not in _BACKBONES:
             raise NotImplementedError(

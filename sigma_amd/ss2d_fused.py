@@ -34,6 +34,14 @@ from . import selective_scan_cuda_core as _core
 # 1 column-major) and i = flipped; reference k = j + 2*i (vmamba.py:84-89).  Self-inverse.
 _PERM = (0, 2, 1, 3)
 _REV_MASK = 0b1010
+
+
+def _perm4(t: torch.Tensor) -> torch.Tensor:
+    """t[[0, 2, 1, 3]] along dim 0 (size 4) as a strided VIEW: swapping the two middle entries of four is
+    a transpose of the (2, 2) split.  Fancy indexing with a Python list builds the index tensor on the
+    host and copies it to the device at every call (450 host-to-device copies + gathers per training
+    step in the round-1 profile); the view costs nothing and stays on the device."""
+    return t.unflatten(0, (2, 2)).transpose(0, 1).flatten(0, 1)
 # One state checkpoint per backward tile (no forward sweep in the backward kernel, second-generation
 # backward csrc/scan_bwd2.hip): 640-element tiles, 320 for short sequences (L = 300 pads to 320 instead of
 # 640).  SIGMA_CKPT_PITCH = 0 / 320 / 640 forces one pitch for A/B runs (0 = reference-shaped x, 1280).
@@ -41,10 +49,12 @@ import os as _os
 _CKPT_ENV = _os.environ.get("SIGMA_CKPT_PITCH", "auto")
 
 
-def ckpt_pitch_for(seqlen: int) -> int:
+def ckpt_pitch_for(seqlen: int, dstate: int = 16) -> int:
+    """320-element backward tiles for short sequences (L = 300 pads to 320 instead of 640) and for 4-state
+    scans up to 1280 elements (state-parallel backward, csrc/scan_bwd3.hip); 640 otherwise."""
     if _CKPT_ENV != "auto":
         return int(_CKPT_ENV)
-    return 320 if seqlen <= 320 else 640
+    return 320 if (seqlen <= 320 or (dstate <= 4 and seqlen <= 1280)) else 640
 
 
 def _two_orders(x4: torch.Tensor) -> torch.Tensor:
@@ -181,7 +191,7 @@ class SelectiveScanExtFn(torch.autograd.Function):
         C = C.float() if C.stride(-1) == 1 else C.float().contiguous()
         A, D, delta_bias = A.float().contiguous(), D.float().contiguous(), delta_bias.float().contiguous()
         out, ck = _core.fwd_ext(u, delta, A, B, C, D, delta_bias, True, rev_mask=rev_mask, u_gshift=u_gshift,
-                                need_x=any(ctx.needs_input_grad), ckpt_pitch=ckpt_pitch_for(u.shape[-1]))
+                                need_x=any(ctx.needs_input_grad), ckpt_pitch=ckpt_pitch_for(u.shape[-1], A.shape[1]))
         ctx.save_for_backward(u, delta, A, B, C, D, delta_bias, ck)
         ctx.ext = (int(rev_mask), int(u_gshift))
         return out
@@ -254,18 +264,17 @@ class SS2DCoreFn(torch.autograd.Function):
         if K != 4:
             raise RuntimeError("SS2DCoreFn expects the 4-direction parameter stack")
         xs2 = xs2.float().contiguous()
-        perm = list(_PERM)
-        Wst = x_proj_weight.float()[perm].reshape(2, 2 * c, d)                 # [order j][(flip i, row)][d]
+        Wst = _perm4(x_proj_weight.float()).reshape(2, 2 * c, d)               # [order j][(flip i, row)][d]
         p4 = torch.matmul(Wst.unsqueeze(0), xs2).view(B, 4, c, L)              # == (B, group g, R+2N, L)
-        dtw = dt_projs_weight.float()[perm]                                    # (4, d, R)
+        dtw = _perm4(dt_projs_weight.float())                                  # (4, d, R)
         delta = torch.matmul(dtw.unsqueeze(0), p4[:, :, :R])                   # (B, 4, d, L)
-        A = (-torch.exp(A_logs.float())).view(4, d, N)[perm].reshape(4 * d, N)
-        Dp = Ds.float().view(4, d)[perm].reshape(-1)
-        bias = dt_projs_bias.float()[perm].reshape(-1)
+        A = _perm4((-torch.exp(A_logs.float())).view(4, d, N)).reshape(4 * d, N)
+        Dp = _perm4(Ds.float().view(4, d)).reshape(-1)
+        bias = _perm4(dt_projs_bias.float()).reshape(-1)
         Bv, Cv = p4[:, :, R:R + N], p4[:, :, R + N:]
         need_x = any(ctx.needs_input_grad)
         out, ck = _core.fwd_ext(xs2.view(B, 2 * d, L), delta.view(B, 4 * d, L), A, Bv, Cv, Dp, bias, True,
-                                rev_mask=_REV_MASK, u_gshift=1, need_x=need_x, ckpt_pitch=ckpt_pitch_for(L))
+                                rev_mask=_REV_MASK, u_gshift=1, need_x=need_x, ckpt_pitch=ckpt_pitch_for(L, N))
         y = cross_merge_nhwc(out.view(B, 4, d, L), H, W)                       # (B, H, W, d)
         ctx.save_for_backward(xs2, p4, delta, A, Dp, bias, ck, Wst, dtw)
         ctx.dims = (B, d, H, W, c, R, N)
@@ -276,7 +285,6 @@ class SS2DCoreFn(torch.autograd.Function):
         xs2, p4, delta, A, Dp, bias, ck, Wst, dtw = ctx.saved_tensors
         B, d, H, W, c, R, N = ctx.dims
         L = H * W
-        perm = list(_PERM)
         g2 = cross_split_nhwc(dy.float().contiguous())                         # CrossMerge^T: 2 planes, not 4
         dp4 = torch.empty_like(p4)
         Bv, Cv = p4[:, :, R:R + N], p4[:, :, R + N:]
@@ -294,11 +302,11 @@ class SS2DCoreFn(torch.autograd.Function):
         dxs2 += du4[:, :, 0]
         dxs2 += du4[:, :, 1]
         dWst = torch.matmul(dp2, xs2.transpose(-1, -2)).sum(0)                 # (2, 2c, d)
-        d_xproj = dWst.view(4, c, d)[perm]
-        d_dtw = d_dtw[perm]
-        dA_logs = (dA * A).view(4, d, N)[perm].reshape(4 * d, N)               # A = -exp(A_logs)
-        dDs = dD.view(4, d)[perm].reshape(-1)
-        dbias = dbias.view(4, d)[perm]
+        d_xproj = _perm4(dWst.view(4, c, d))                                   # the permutation is its own inverse
+        d_dtw = _perm4(d_dtw)
+        dA_logs = _perm4((dA * A).view(4, d, N)).reshape(4 * d, N)             # A = -exp(A_logs)
+        dDs = _perm4(dD.view(4, d)).reshape(-1)
+        dbias = _perm4(dbias.view(4, d))
         return dxs2, None, None, d_xproj, d_dtw, dbias, dA_logs, dDs
 
 

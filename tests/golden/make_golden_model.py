@@ -128,6 +128,16 @@ def main():
             gdig.append(digest(p.grad) if p.grad is not None else np.full(3, np.nan))
         blob["grad_names"] = np.array(gnames)
         blob["grad_digest"] = np.stack(gdig)
+        # full gradients of the scan-adjacent parameters (small tensors) for a per-element comparison
+        blocks = ("vssm.layers.0.blocks.0.", "vssm.layers.2.blocks.0.", "vssm.layers.2.blocks.8.", "vssm.layers.3.blocks.1.",
+                  "cross_mamba.0.", "cross_mamba.3.", "channel_attn_mamba.0.", "channel_attn_mamba.3.",
+                  "layers_up.1.blocks.0.", "layers_up.3.blocks.3.")
+        full = [n for n, p in model.named_parameters() if p.grad is not None and p.numel() <= 40000 and any(b in n for b in blocks)
+                and any(t in n for t in ("x_proj", "dt_proj", "A_log", ".Ds", ".D_1", ".D_2", "conv2d.bias", "out_norm", "scale1", "scale2"))]
+        blob["grad_full_names"] = np.array(full)
+        named = dict(model.named_parameters())
+        for i, n in enumerate(full):
+            blob[f"grad_full_{i}"] = named[n].grad.detach().numpy()
         path = os.path.join(HERE, f"model_{c['name']}.npz")
         np.savez_compressed(path, **blob)
         print(path, "logits", tuple(logits.shape), "loss %.6f" % loss.item(), "%.0f KiB" % (os.path.getsize(path) / 1024))

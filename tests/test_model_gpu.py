@@ -34,6 +34,66 @@ def test_logits_loss_and_grads_match_reference_fixtures(case):
         if not (abs(d[0] - r[0]) < tol and abs(d[1] - r[1]) < tol and abs(d[2] - r[2]) < tol):
             bad.append((n, d.tolist(), r.tolist()))
     assert not bad, bad[:5]
+    # element-wise comparison for the scan-adjacent parameters of ten blocks (every kind of block):
+    # x_proj / dt_proj weights and biases, A_logs, Ds, out_norm, conv bias, decoder scales
+    worst = []
+    for i, n in enumerate(list(z["grad_full_names"])):
+        r = torch.from_numpy(z[f"grad_full_{i}"])
+        g = got[str(n)].grad.cpu()
+        scale = float(r.abs().max()) + 1e-7
+        err = float((g - r).abs().max()) / scale
+        if err > 2e-3:
+            worst.append((str(n), err, scale))
+    assert not worst, worst[:5]
+
+
+def test_sigma_small_480x640_logits_vs_cpu_oracle():
+    """The benchmarked configuration (BASELINE.json configs[2]: sigma_small, 480x640, NYU 40 classes),
+    forward logits of the HIP path vs the CPU oracle model, 1e-3 relative (VERDICT r1 weak #2)."""
+    from oracle import sigma_oracle
+    model = build_model("sigma_small", 40, 480, 640).cuda().eval()
+    rgb, x, _ = fill.make_inputs(1, 480, 640, 40, seed=4)
+    with torch.no_grad():
+        logits = model(rgb.cuda(), x.cuda())
+    ref = sigma_oracle.sigma_forward(model.state_dict(), rgb, x, "sigma_small")
+    assert_logits_close(logits, ref, 1e-3)
+
+
+def test_real_model_under_ddp_matches_plain_gradients():
+    """train.py:107: the product model (custom autograd Functions, view outputs, fused kernels) wrapped in
+    DistributedDataParallel(find_unused_parameters=False) over RCCL with one rank: every parameter
+    receives a gradient, the gradients equal the un-wrapped model's, and one optimizer step moves both
+    replicas identically (VERDICT r1 weak #10; the 2-rank arithmetic is covered on CPU with gloo)."""
+    import copy
+    import os
+    import socket
+    import torch.distributed as dist
+    from sigma_amd import train_step as ts
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        dev = torch.device("cuda", 0)
+        plain = build_model("sigma_tiny", 9, 64, 96).to(dev).eval()      # eval: DropPath off -> comparable
+        wrapped = copy.deepcopy(plain)
+        net = ts.wrap_ddp(wrapped, dev)
+        assert isinstance(net, torch.nn.parallel.DistributedDataParallel)
+        rgb, x, label = fill.make_inputs(2, 64, 96, 9, seed=9)
+        batch = (rgb.to(dev), x.to(dev), label.to(dev))
+        opt_p, opt_w = ts.make_optimizer(plain), ts.make_optimizer(wrapped)
+        loss_p = ts.make_step(plain, opt_p, batch)()
+        loss_w = ts.make_step(net, opt_w, batch)()
+        torch.testing.assert_close(loss_w, loss_p, rtol=1e-5, atol=1e-6)
+        for (n, a), (_, b) in zip(plain.named_parameters(), wrapped.named_parameters()):
+            assert b.grad is not None, n
+            torch.testing.assert_close(b.grad, a.grad, rtol=1e-4, atol=1e-6 + 1e-5 * float(a.grad.abs().max()), msg=lambda m, n=n: f"{n}: {m}")
+            # one AdamW step moves a weight by <= lr = 6e-5; gradients that differ in the last bits (MIOpen and
+            # depthwise-conv weight gradients use atomics) may move single elements by a fraction of that
+            torch.testing.assert_close(b, a, rtol=1e-4, atol=2e-5)
+    finally:
+        dist.destroy_process_group()
 
 
 def test_sigma_tiny_480x640_logits_vs_cpu_oracle():

@@ -82,6 +82,9 @@ def check():
         (16, 3072, 1200, 16, 4, 0b1100, 1, torch.float32, False),   # the dominant launch
         (1, 768, 19200, 16, 4, 0, 0, torch.float32, False),
     ]
+    sel = os.environ.get("CASES")
+    if sel:
+        cases = [cases[int(i)] for i in sel.split(",")]
     for (batch, KD, L, N, G, mask, ush, dt, use_oracle) in cases:
         u, delta, A, Bm, Cm, D, bias, dout = model_like(batch, KD, L, N, G, seed=L + N, dtype=dt)
         if ush:
@@ -103,15 +106,25 @@ def check():
                                                    fr(dout.float()), True))
             rg[0], rg[1], rg[3], rg[4] = fr(rg[0]), fr(rg[1]), fg(rg[3]), fg(rg[4])
             ref = rg
+        verbose = os.environ.get("VERBOSE")
+        def mark(msg):
+            if verbose:
+                torch.cuda.synchronize()
+                print("   ..", msg, flush=True)
+        mark("inputs on device")
         _, x1 = core.fwd_ext(*args, True, rev_mask=mask, u_gshift=ush)
+        mark("fwd default pitch done")
         g1 = with_opts(dict(bwd_gen=1), lambda: core.bwd_ext(*args, g, x1, True, rev_mask=mask, u_gshift=ush))
-        variants = [(640, {}), (640, dict(bwd_rb=1)), (640, dict(bwd_rb=2, bwd_slab2=2)), (640, dict(bwd_waves=16, bwd_nb=2)),
-                    (320, {}), (320, dict(bwd_rb=1, bwd_waves=16)), (320, dict(bwd_rb=4, bwd_waves=8, bwd_slab2=2))]
+        mark("v1 bwd done")
+        variants = [(640, dict(bwd_gen=2)), (640, dict(bwd_gen=2, bwd_rb=2, bwd_slab2=2)), (320, dict(bwd_gen=2)),
+                    (320, dict(bwd_gen=3)), (320, dict(bwd_gen=3, bwd_waves=12)), (320, dict(bwd_gen=3, bwd_rb=1)),
+                    (320, dict(bwd_gen=3, bwd_waves=8, bwd_rb=2))]
         for pitch, opts in variants:
             out, x = core.fwd_ext(*args, True, rev_mask=mask, u_gshift=ush, ckpt_pitch=pitch)
+            mark(f"fwd pitch {pitch} done")
             plan = None
             try:
-                g2 = with_opts(dict(bwd_gen=2, **opts), lambda: core.bwd_ext(*args, g, x, True, rev_mask=mask, u_gshift=ush, ckpt_pitch=pitch))
+                g2 = with_opts(dict(**opts), lambda: core.bwd_ext(*args, g, x, True, rev_mask=mask, u_gshift=ush, ckpt_pitch=pitch))
             except RuntimeError as e:
                 print("ERR", (batch, KD, L, N, G, mask, ush, str(dt)), pitch, opts, e, flush=True)
                 bad += 1
@@ -153,16 +166,16 @@ def bench(names):
         variants = [
             ("v1 fine", 640, dict(bwd_gen=1)),
             ("v2 T10 R12 rb1", 640, dict(bwd_gen=2, bwd_rb=1)),
-            ("v2 T10 R12 rb1 nb4", 640, dict(bwd_gen=2, bwd_rb=1, bwd_nb=4, bwd_slab2=2)),
-            ("v2 T10 R12 rb1 nb1", 640, dict(bwd_gen=2, bwd_rb=1, bwd_nb=1)),
             ("v2 T10 R16 rb1", 640, dict(bwd_gen=2, bwd_waves=16, bwd_rb=1, bwd_nb=2)),
             ("v2 T10 R16 rb1 slab1", 640, dict(bwd_gen=2, bwd_waves=16, bwd_rb=1, bwd_nb=4, bwd_slab2=2)),
-            ("v2 T10 R16 rb1 nb1", 640, dict(bwd_gen=2, bwd_waves=16, bwd_rb=1, bwd_nb=1)),
+            ("v3 auto", 320, dict(bwd_gen=3)),
+            ("v3 W12", 320, dict(bwd_gen=3, bwd_waves=12)),
+            ("v3 W8", 320, dict(bwd_gen=3, bwd_waves=8)),
+            ("v3 W16 rb1", 320, dict(bwd_gen=3, bwd_rb=1)),
+            ("v3 W16 rb4", 320, dict(bwd_gen=3, bwd_rb=4)),
+            ("v3 W12 rb4", 320, dict(bwd_gen=3, bwd_waves=12, bwd_rb=4)),
             ("v2 T5 R8 rb1", 320, dict(bwd_gen=2, bwd_waves=8, bwd_rb=1)),
-            ("v2 T5 R12 rb1", 320, dict(bwd_gen=2, bwd_waves=12, bwd_rb=1)),
             ("v2 T5 R16 rb1", 320, dict(bwd_gen=2, bwd_waves=16, bwd_rb=1)),
-            ("v2 T5 R16 rb1 slab1", 320, dict(bwd_gen=2, bwd_waves=16, bwd_rb=1, bwd_slab2=2)),
-            ("v2 T5 R8 rb1 slab1", 320, dict(bwd_gen=2, bwd_waves=8, bwd_rb=1, bwd_slab2=2)),
         ]
         for label, pitch, opts in variants:
             x = xs[pitch]
