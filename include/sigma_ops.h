@@ -85,6 +85,14 @@ typedef struct sigma_transpose_params {
 
 int sigma_transpose2d(const sigma_transpose_params *params, void *stream);
 
+/*   sigma_pair_sum_add
+ *       acc[o][i] += src[2*o][i] + src[2*o + 1][i]  for o < n_outer, i < inner (contiguous fp32).
+ *       Adjoint of reading ONE copy of x for the two directions of a memory order (u_group_shift = 1 in
+ *       sigma_scan.h): du of the forward and of the flipped direction are added to the x_proj part of the
+ *       gradient in one pass (autograd of the reference's CrossScan does it with flips and adds,
+ *       vmamba.py:91-98); replaces two strided torch adds.                                        */
+int sigma_pair_sum_add(const float *src, float *acc, int64_t n_outer, int64_t inner, void *stream);
+
 /*   sigma_layernorm_fwd / sigma_layernorm_bwd
  *       nn.LayerNorm(C, eps=1e-5, affine) over the last dimension of a contiguous (rows, C) fp32
  *       tensor: every LayerNorm of the hot path (vmamba.py:617, 724, 1183-1184, 1448-1449, 1693,

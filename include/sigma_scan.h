@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SIGMA_SCAN_ABI_VERSION 5
+#define SIGMA_SCAN_ABI_VERSION 6
 
 /* dtype of u, delta, B, C, out, dout, du, ddelta  (input_t of the reference,
  * selective_scan.cpp:174: float / half / bfloat16).  A, D, delta_bias, x, dA,
@@ -96,7 +96,11 @@ typedef struct sigma_scan_fwd_params {
     uint32_t rev_group_mask;
     int32_t u_group_shift;
     int32_t ckpt_pitch;        /* 0 = SIGMA_SCAN_CKPT_PITCH (1280); 640 / 320 = fine checkpoints (see above) */
-    int32_t reserved0_;
+    int32_t param_group_swap;  /* 1 (needs n_groups == 4): A, D, delta_bias and dA, dD, ddelta_bias keep the REFERENCE's direction
+                                  order k = [row, col, row reversed, col reversed] (vmamba.py:84-89) while the sequence
+                                  operands use the kernel's group order g = 2*order + reversed: group g reads / writes the
+                                  parameter rows of group ((g & 1) << 1) | (g >> 1).  Spares the caller six small
+                                  permutation copies per call. */
     int64_t x_row_stride;      /* floats per (batch, row) of x; 0 = n_chunks * 2 * dstate */
     /* inputs */
     const void *u;            /* (B, dim, L)        io_dtype */

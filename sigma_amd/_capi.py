@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SIGMA_HIP_LIB lets a benchmark A/B an experimental build of the same ABI; default is the in-tree library
 LIB_PATH = os.environ.get("SIGMA_HIP_LIB") or os.path.join(_HERE, "lib", "libsigma_hip.so")
 
-SIGMA_SCAN_ABI_VERSION = 5
+SIGMA_SCAN_ABI_VERSION = 6
 SIGMA_SCAN_CHUNK = 2048
 SIGMA_SCAN_CKPT_PITCH = 1280
 SIGMA_SCAN_CKPT_PITCH_FINE = 640
@@ -34,7 +34,7 @@ class FwdParams(ctypes.Structure):
         ("dstate", ctypes.c_int32), ("n_groups", ctypes.c_int32), ("n_chunks", ctypes.c_int32),
         ("io_dtype", ctypes.c_int32), ("delta_softplus", ctypes.c_int32),
         ("rev_group_mask", ctypes.c_uint32), ("u_group_shift", ctypes.c_int32),
-        ("ckpt_pitch", ctypes.c_int32), ("reserved0_", ctypes.c_int32), ("x_row_stride", ctypes.c_int64),
+        ("ckpt_pitch", ctypes.c_int32), ("param_group_swap", ctypes.c_int32), ("x_row_stride", ctypes.c_int64),
         ("u", ctypes.c_void_p), ("delta", ctypes.c_void_p), ("A", ctypes.c_void_p),
         ("B", ctypes.c_void_p), ("C", ctypes.c_void_p), ("D", ctypes.c_void_p),
         ("delta_bias", ctypes.c_void_p),
@@ -109,7 +109,8 @@ class LayerNormParams(ctypes.Structure):
 
 # every symbol include/sigma_ops.h declares
 OPS_SYMBOLS = ("sigma_dwconv3x3_silu_fwd", "sigma_dwconv3x3_silu_bwd", "sigma_cross_merge_nhwc", "sigma_cross_split_nhwc",
-               "sigma_layernorm_fwd", "sigma_layernorm_bwd", "sigma_layernorm_bwd_partial_rows", "sigma_transpose2d")
+               "sigma_layernorm_fwd", "sigma_layernorm_bwd", "sigma_layernorm_bwd_partial_rows", "sigma_transpose2d",
+               "sigma_pair_sum_add")
 
 # every symbol include/sigma_scan.h declares; tests check the library exports all of them
 EXPORTED_SYMBOLS = (
@@ -169,6 +170,8 @@ def load() -> ctypes.CDLL:
         fn = getattr(lib, name)
         if name == "sigma_layernorm_bwd_partial_rows":
             fn.argtypes = [ctypes.c_int64]
+        elif name == "sigma_pair_sum_add":
+            fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]
         else:
             st = (MergeParams if "cross_" in name else LayerNormParams if "layernorm" in name else
                   TransposeParams if "transpose" in name else DwConvParams)

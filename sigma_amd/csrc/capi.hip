@@ -65,6 +65,9 @@ int check_fwd(const sigma_scan_fwd_params* p, bool need_out, bool need_ptrs = tr
             return fail(SIGMA_ERR_BAD_SHAPE, "x_row_stride %lld too small for %lld checkpoint floats per row",
                         (long long)have, (long long)need);
     }
+    if (p->param_group_swap != 0 && (p->param_group_swap != 1 || p->n_groups != 4))
+        return fail(SIGMA_ERR_BAD_SHAPE, "param_group_swap must be 0, or 1 with n_groups == 4 (got %d, %d groups)",
+                    p->param_group_swap, p->n_groups);
     if (p->u_group_shift < 0 || p->u_group_shift > 5)
         return fail(SIGMA_ERR_BAD_SHAPE, "u_group_shift must be in [0, 5] (got %d)", p->u_group_shift);
     if (p->batch == 0 || p->seqlen == 0 || !need_ptrs) return SIGMA_OK;
@@ -96,6 +99,7 @@ sigma::FwdArgs make_fwd_args(const sigma_scan_fwd_params* p, int R, int W, int N
     a.R = R; a.W = W; a.NB = NB;
     a.rev_mask = p->rev_group_mask;
     a.u_gshift = p->u_group_shift;
+    a.pswap = p->param_group_swap;
     a.ckpt_pitch = p->ckpt_pitch ? p->ckpt_pitch : sigma::kCkptPitch;
     a.x_rs = p->x_row_stride ? p->x_row_stride : (long)p->n_chunks * 2 * p->dstate;
     a.u_bs = p->u_batch_stride; a.u_ds = p->u_d_stride; a.dt_bs = p->delta_batch_stride; a.dt_ds = p->delta_d_stride;
@@ -268,15 +272,11 @@ Plan2 plan_bwd2(const sigma_scan_fwd_params* p, bool vec) {
     const int tile = 64 * T;
     const int rpg = p->dim / p->n_groups;
     const int fr = g_opt_bwd_waves.load();
-    // measured (tools/bwd2_check.py bench, profiles/r02_bwd2_variants.txt): with 16 states and enough rows
-    // the 16-wave workgroup wins although T = 10 then spills (4 waves per SIMD beat 3); few-state scans and
-    // small batches prefer 12 rows; 320-tiles prefer 8-row workgroups (two per CU)
-    static const int pref16[] = {16, 12, 8, 6, 10, 14, 15, 11, 13, 9, 7, 5};
+    // measured (tools/bwd2_check.py bench, profiles/r02_bwd2_variants.txt): 640-tiles run best with 12-row workgroups
+    // (168 VGPRs, no spills; the LDS accumulators of the row-block loop do not fit beside 16 slabs), 320-tiles with 16
     static const int pref12[] = {12, 16, 8, 6, 10, 14, 15, 11, 13, 9, 7, 5};
-    static const int pref8[] = {8, 16, 12, 6, 10, 14, 15, 11, 13, 9, 7, 5};
-    const bool many16 = (long)p->batch * p->dim / 16 >= 2L * kCUs;
-    const int* pref = (p->dstate > 8 && many16) ? pref16 : pref12;
-    (void)pref8;
+    static const int pref16[] = {16, 12, 8, 6, 10, 14, 15, 11, 13, 9, 7, 5};
+    const int* pref = T == 5 ? pref16 : pref12;
     int R = 0;
     if (fr > 0 && fr <= 16 && rpg % fr == 0 && fr * 64 >= tile) R = fr;
     for (int i = 0; R == 0 && i < 12; ++i)
@@ -285,23 +285,26 @@ Plan2 plan_bwd2(const sigma_scan_fwd_params* p, bool vec) {
     int NB = g_opt_bwd_nb.load() > 0 ? g_opt_bwd_nb.load() : 4;
     if (NB > p->dstate) NB = p->dstate;
     const int rowblocks = rpg / R;
-    // Row blocks per workgroup ("bwd_rb" > 1): the dB/dC sums of RB row blocks meet in per-thread
-    // accumulators.  Off by default: at T = 10 the 8T + 45 live values leave no room for 2N more
-    // registers, hipcc parks the accumulators in scratch and the kernel gets slower (measured 1499 vs
-    // 1422 us on (16,3072,1200,N16)); the option stays for the A/B.
+    // Row blocks per workgroup ("bwd_rb"): the dB/dC sums of RB row blocks meet in LDS accumulators
+    // (2 * N * tile floats) before they leave the workgroup: RB times fewer partial slabs in the workspace.
+    // as many row blocks per workgroup as still leave one workgroup per CU (measured: -5 ... -15 % on the
+    // 16-state shapes, and the reduce_partials pass shrinks with the slab count); "bwd_rb" forces a value
     int RB = 1;
     const int frb = g_opt_bwd_rb.load();
-    if (frb > 1) {
+    if (frb > 0) {
         RB = frb;
         while (RB > 1 && rowblocks % RB != 0) --RB;
+    } else {
+        for (int d = 1; d <= rowblocks; ++d)
+            if (rowblocks % d == 0 && (long)p->batch * p->n_groups * (rowblocks / d) >= kCUs) RB = d;
     }
-    int nacc = RB == 1 ? 0 : (p->dstate <= 4 ? 4 : (p->dstate <= 16 ? 16 : -1));
-    if (nacc < 0) { RB = 1; nacc = 0; }
+    const int nacc = 0;
     const int sl = g_opt_bwd_slab2.load();
     bool slab2 = sl != 2;                                            // two slab sets when they fit beside NB = 4
     while (sigma::bwd2_lds_bytes(T, R, NB, p->dstate, slab2, RB) > kLdsLimit) {
         if (slab2) slab2 = false;
         else if (NB > 1) NB >>= 1;
+        else if (RB > 1) { --RB; while (RB > 1 && rowblocks % RB != 0) --RB; }
         else return pl;
     }
     pl.ok = true;
@@ -532,7 +535,7 @@ int sigma_selective_scan_bwd(const sigma_scan_bwd_params* q, void* stream) {
     a.ws_dC = P > 1 ? static_cast<float*>(q->workspace) + slab : nullptr;
     a.flags = g_opt_bwd_notouch.load() ? 1 : 0;
     a.RB = p3.ok ? p3.RB : (p2.ok ? p2.RB : 1);
-    hipError_t e = p3.ok ? sigma::launch_scan_bwd3(a, p->io_dtype, pl.glds, static_cast<hipStream_t>(stream)) : p2.ok ? sigma::launch_scan_bwd2(a, p->io_dtype, pl.items, pl.glds, p2.nacc, static_cast<hipStream_t>(stream))
+    hipError_t e = p3.ok ? sigma::launch_scan_bwd3(a, p->io_dtype, pl.glds, static_cast<hipStream_t>(stream)) : p2.ok ? sigma::launch_scan_bwd2(a, p->io_dtype, pl.items, pl.glds, static_cast<hipStream_t>(stream))
                          : sigma::launch_scan_bwd(a, p->io_dtype, pl.items, pl.glds, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(SIGMA_ERR_LAUNCH, "scan_bwd launch failed: %s", hipGetErrorString(e));
     return SIGMA_OK;

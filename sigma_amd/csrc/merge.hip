@@ -151,7 +151,47 @@ bool grid_for(const sigma_merge_params* p, unsigned* grid) {
 
 }  // namespace sigma
 
+namespace sigma {
+namespace {
+// acc[o][i] += src[2o][i] + src[2o+1][i]; 16 bytes per lane, grid-stride over (o, i / 4)
+__global__ void __launch_bounds__(256)
+pair_sum_add_kernel(const float* __restrict__ src, float* __restrict__ acc, long n_outer, long inner, int vec) {
+    if (vec) {
+        const long inner4 = inner >> 2;
+        const long total = n_outer * inner4;
+        for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+            const long o = t / inner4, i4 = t - o * inner4;
+            const float4 a = reinterpret_cast<const float4*>(src + (2 * o) * inner)[i4];
+            const float4 b = reinterpret_cast<const float4*>(src + (2 * o + 1) * inner)[i4];
+            float4* dst = reinterpret_cast<float4*>(acc + o * inner) + i4;
+            float4 c = *dst;
+            c.x += a.x + b.x; c.y += a.y + b.y; c.z += a.z + b.z; c.w += a.w + b.w;
+            *dst = c;
+        }
+    } else {
+        const long total = n_outer * inner;
+        for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+            const long o = t / inner, i = t - o * inner;
+            acc[t] += src[(2 * o) * inner + i] + src[(2 * o + 1) * inner + i];
+        }
+    }
+}
+}  // namespace
+}  // namespace sigma
+
 extern "C" {
+
+int sigma_pair_sum_add(const float* src, float* acc, int64_t n_outer, int64_t inner, void* stream) {
+    if (!src || !acc || n_outer < 0 || inner < 0) return SIGMA_OPS_ERR_ARG;
+    if (n_outer == 0 || inner == 0) return SIGMA_OPS_OK;
+    const int vec = (inner % 4 == 0) && (reinterpret_cast<uintptr_t>(src) % 16 == 0) && (reinterpret_cast<uintptr_t>(acc) % 16 == 0);
+    const long work = vec ? n_outer * (inner / 4) : n_outer * inner;
+    long blocks = (work + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(sigma::pair_sum_add_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), src, acc,
+                       (long)n_outer, (long)inner, vec);
+    return hipGetLastError() == hipSuccess ? SIGMA_OPS_OK : SIGMA_OPS_ERR_LAUNCH;
+}
 
 int sigma_cross_merge_nhwc(const sigma_merge_params* p, void* stream) {
     unsigned grid = 0;

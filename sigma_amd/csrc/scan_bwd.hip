@@ -94,9 +94,10 @@ __device__ __forceinline__ void scan_bwd_body(const BwdArgs& q, float* smem, int
     const io_t* __restrict__ Cg = reinterpret_cast<const io_t*>(p.C) + (long)b * p.C_bs + (long)g * p.C_gs;
     float* __restrict__ dBg = q.dB + (long)b * q.dB_bs + (long)g * q.dB_gs;
     float* __restrict__ dCg = q.dC + (long)b * q.dC_bs + (long)g * q.dC_gs;
-    const float* __restrict__ A_row = p.A + (long)r * p.A_ds;
-    const float bias = p.bias ? p.bias[r] : 0.0f;
-    const float Dd = p.D ? p.D[r] : 0.0f;
+    const int pr = param_row(r, g, p.rows_per_group, p.pswap);
+    const float* __restrict__ A_row = p.A + (long)pr * p.A_ds;
+    const float bias = p.bias ? p.bias[pr] : 0.0f;
+    const float Dd = p.D ? p.D[pr] : 0.0f;
     const float* __restrict__ x_row = p.x ? p.x + ((long)b * p.dim + r) * p.x_rs : nullptr;
 
     const long ws_slab = (q.P > 1)
@@ -385,11 +386,11 @@ __device__ __forceinline__ void scan_bwd_body(const BwdArgs& q, float* smem, int
     dD_acc = wave_sum(dD_acc);
     dbias_acc = wave_sum(dbias_acc);
     if (lane == 0) {
-        if (q.dD) atomicAdd(q.dD + r, dD_acc);
-        if (q.dbias) atomicAdd(q.dbias + r, dbias_acc);
+        if (q.dD) atomicAdd(q.dD + pr, dD_acc);
+        if (q.dbias) atomicAdd(q.dbias + pr, dbias_acc);
     }
     for (int n = lane; n < N; n += 64)
-        atomicAdd(q.dA + (long)r * q.dA_ds + (long)n * q.dA_ns, sdA[wave * N + n]);
+        atomicAdd(q.dA + (long)pr * q.dA_ds + (long)n * q.dA_ns, sdA[wave * N + n]);
 }
 
 // T = 10 keeps ~90 values per lane live (5 per-element accumulators + a, x, g*C per state): it

@@ -8,9 +8,9 @@
 //
 // What changed against scan_bwd.hip, and why (profiles/r01_final_pmc_enc_s2_b16.txt):
 //   * ROW-BLOCK LOOP: a workgroup owns RB*R rows of one (batch, group) and walks them R at a time
-//     for every tile, so the dB/dC partial sums of RB row blocks meet in REGISTERS of the
-//     column-sum threads (acc[n], one float2 per state) instead of in P = rows/R global slabs.
-//     The workspace shrinks by RB (64 -> 4 slabs on the dominant shape) or disappears (P == 1);
+//     for every tile, so the dB/dC partial sums of RB row blocks meet in LDS (one float2 per state
+//     and column, private to the column-sum thread that owns the column) instead of in P = rows/R
+//     global slabs.  The workspace shrinks by RB (64 -> 8 slabs on the dominant shape) or disappears;
 //   * the wave scans carry the decay as a product (v_fmac_f32_dpp + v_mul_f32_dpp without
 //     bound_ctrl): no v_exp_f32 inside a scan step (8 cycles each vs 2.25 for a plain VALU op,
 //     tools/ubench), ONE exp2 per lane and state for the lane's decay product, shared by the
@@ -163,7 +163,7 @@ __device__ __forceinline__ float2 colsum(const float* __restrict__ colp, int str
 
 }  // namespace
 
-template <typename io_t, int T, bool GLDS, bool REV, int NACC>
+template <typename io_t, int T, bool GLDS, bool REV>
 __device__ __forceinline__ void scan_bwd2_body(const BwdArgs& q, float* smem, int b, int g, int chunk) {
     constexpr int TILE = 64 * T;
     constexpr int VW = vec_width<T>::value;
@@ -227,9 +227,10 @@ __device__ __forceinline__ void scan_bwd2_body(const BwdArgs& q, float* smem, in
     const bool col_on = tid < TILE;
     const int col_c = tid / (TILE / 2);
     const int col_pp = (tid - col_c * (TILE / 2)) * 2;
-    float2 acc[NACC > 0 ? NACC : 1];
-#pragma unroll
-    for (int i = 0; i < (NACC > 0 ? NACC : 1); ++i) acc[i] = make_float2(0.f, 0.f);
+    // RB > 1: the column sums of the row blocks of a tile meet in LDS, one float2 per state and column,
+    // touched only by the thread that owns the column (no barrier, no atomics): the first row block
+    // stores, the middle ones add, the last one adds and writes the total to memory.
+    float* sAcc = sRv + RB * R * N + 64;               // [N][2][TILE] when RB > 1
 
     // write one float2 column of state n (positions pp, pp+1 of the tile starting at l0)
     auto put_col = [&](int n, int l0, float2 v) {
@@ -265,13 +266,14 @@ __device__ __forceinline__ void scan_bwd2_body(const BwdArgs& q, float* smem, in
             const io_t* __restrict__ u_row = reinterpret_cast<const io_t*>(kq->f.u) + (long)b * kq->f.u_bs + (long)ur * kq->f.u_ds;
             const io_t* __restrict__ d_row = reinterpret_cast<const io_t*>(kq->f.delta) + (long)b * kq->f.dt_bs + (long)r * kq->f.dt_ds;
             const io_t* __restrict__ g_row = reinterpret_cast<const io_t*>(kq->dout) + (long)b * kq->g_bs + (long)gr * kq->g_ds;
-            const float bias = kq->f.bias ? kq->f.bias[r] : 0.0f;
+            const int pr = param_row(r, g, rpg, kq->f.pswap);
+            const float bias = kq->f.bias ? kq->f.bias[pr] : 0.0f;
 
             // lane vectors (lane n = state n): A[r, :], the state entering the tile, the reverse carry.
             // Loaded first: older than the row loads below, so complete once those have been consumed.
             float Av = 0.0f, X0v = 0.0f, Rvv = 0.0f, rvout_v = 0.0f, dA_v = 0.0f;
             if (lane < N) {
-                Av = kq->f.A[(long)r * kq->f.A_ds + (long)lane * kq->f.A_ns];
+                Av = kq->f.A[(long)pr * kq->f.A_ds + (long)lane * kq->f.A_ns];
                 if (j > 0) X0v = kq->f.x[((long)b * kq->f.dim + r) * kq->f.x_rs + (long)(j - 1) * N + lane];
                 Rvv = sRv[rl * N + lane];
             }
@@ -407,8 +409,15 @@ __device__ __forceinline__ void scan_bwd2_body(const BwdArgs& q, float* smem, in
                     PROF(6)                                    // barrier wait
                     if (col_on) {
                         const float2 s = colsum(sRedN + col_c * TILE + col_pp, 2 * TILE, R);
-                        if constexpr (NACC > 0) {
-                            acc[n].x += s.x; acc[n].y += s.y;
+                        if (RB > 1) {
+                            float2* ap = reinterpret_cast<float2*>(sAcc + (n * 2 + col_c) * TILE + col_pp);
+                            if (rb == 0) {
+                                *ap = s;
+                            } else {
+                                float2 t = *ap;
+                                t.x += s.x; t.y += s.y;
+                                if (rb == RB - 1) put_col(n, l0, t); else *ap = t;
+                            }
                         } else {
                             put_col(n, l0, s);
                         }
@@ -427,15 +436,15 @@ __device__ __forceinline__ void scan_bwd2_body(const BwdArgs& q, float* smem, in
             const io_t* __restrict__ d_row2 = reinterpret_cast<const io_t*>(ke->f.delta) + (long)b * ke->f.dt_bs + (long)r * ke->f.dt_ds;
             if (lane < N) {
                 sRv[rl * N + lane] = rvout_v;
-                atomicAdd(ke->dA + (long)r * ke->dA_ds + (long)lane * ke->dA_ns, dA_v);
+                atomicAdd(ke->dA + (long)pr * ke->dA_ds + (long)lane * ke->dA_ns, dA_v);
             }
             float duv[T], ddv[T];
             float dD_acc = 0.0f, dbias_acc = 0.0f;
             {
                 // softplus' = sigmoid(raw) and the u factors: re-read delta and u (L2-resident) instead
                 // of holding 2T registers across the whole state loop
-                const float Dd = ke->f.D ? ke->f.D[r] : 0.0f;
-                const float bias2 = ke->f.bias ? ke->f.bias[r] : 0.0f;
+                const float Dd = ke->f.D ? ke->f.D[pr] : 0.0f;
+                const float bias2 = ke->f.bias ? ke->f.bias[pr] : 0.0f;
                 float dv2[T], uu[T];
                 load_items<io_t, T, REV>(d_row2, lbase, L, vec, dv2);
                 load_items<io_t, T, REV>(u_row2, lbase, L, vec, uu);
@@ -456,24 +465,15 @@ __device__ __forceinline__ void scan_bwd2_body(const BwdArgs& q, float* smem, in
             io_t* __restrict__ dd_row = reinterpret_cast<io_t*>(ke->ddelta) + (long)b * ke->dd_bs + (long)r * ke->dd_ds;
             store_items<io_t, T, REV>(du_row, lbase, L, vec, duv);
             store_items<io_t, T, REV>(dd_row, lbase, L, vec, ddv);
-            if (ke->dD) { dD_acc = wave_sum(dD_acc); if (lane0) atomicAdd(ke->dD + r, dD_acc); }
-            if (ke->dbias) { dbias_acc = wave_sum(dbias_acc); if (lane0) atomicAdd(ke->dbias + r, dbias_acc); }
+            if (ke->dD) { dD_acc = wave_sum(dD_acc); if (lane0) atomicAdd(ke->dD + pr, dD_acc); }
+            if (ke->dbias) { dbias_acc = wave_sum(dbias_acc); if (lane0) atomicAdd(ke->dbias + pr, dbias_acc); }
             PROF(8)                                            // row epilogue
         }
-        if constexpr (NACC > 0) {
-            if (col_on) {
-#pragma unroll
-                for (int n = 0; n < NACC; ++n) {
-                    if (n < N) { put_col(n, l0, acc[n]); acc[n] = make_float2(0.f, 0.f); }
-                }
-            }
-        }
-        PROF(9)                                                // accumulator flush
     }
     PROF_FLUSH
 }
 
-template <typename io_t, int T, bool GLDS, int NACC, int MAXW>
+template <typename io_t, int T, bool GLDS, int MAXW>
 __global__ void __launch_bounds__(64 * MAXW)
 scan_bwd2_kernel(const BwdArgs q) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -483,15 +483,15 @@ scan_bwd2_kernel(const BwdArgs q) {
     const int rem = lb - b * per_b;
     const int g = rem / q.P;
     const int chunk = rem - g * q.P;
-    if ((q.f.rev_mask >> g) & 1u) scan_bwd2_body<io_t, T, GLDS, true, NACC>(q, smem, b, g, chunk);
-    else scan_bwd2_body<io_t, T, GLDS, false, NACC>(q, smem, b, g, chunk);
+    if ((q.f.rev_mask >> g) & 1u) scan_bwd2_body<io_t, T, GLDS, true>(q, smem, b, g, chunk);
+    else scan_bwd2_body<io_t, T, GLDS, false>(q, smem, b, g, chunk);
 }
 
-template <typename io_t, int T, bool GLDS, int NACC, int MAXW>
+template <typename io_t, int T, bool GLDS, int MAXW>
 static hipError_t launch_bwd2_t(const BwdArgs& a, hipStream_t stream) {
     const size_t lds = bwd2_lds_bytes(T, a.f.R, a.f.NB, a.f.N, a.slab2 != 0, a.RB);
     const int grid = a.f.batch * a.f.G * a.P;
-    auto kern = scan_bwd2_kernel<io_t, T, GLDS, NACC, MAXW>;
+    auto kern = scan_bwd2_kernel<io_t, T, GLDS, MAXW>;
     // raise the dynamic-LDS cap per device and kernel (the attribute is per device)
     static std::atomic<size_t> lds_cap[kMaxDevices];
     int dev = 0;
@@ -510,30 +510,25 @@ static hipError_t launch_bwd2_t(const BwdArgs& a, hipStream_t stream) {
 }
 
 template <typename io_t, int T, bool GLDS>
-static hipError_t launch_bwd2_acc(const BwdArgs& a, int nacc, hipStream_t stream) {
-    const bool wide = a.f.R > 12;                     // 13..16 waves: 128-VGPR budget
-    switch (nacc) {
-        case 0: return wide ? launch_bwd2_t<io_t, T, GLDS, 0, 16>(a, stream) : launch_bwd2_t<io_t, T, GLDS, 0, 12>(a, stream);
-        case 4: return wide ? launch_bwd2_t<io_t, T, GLDS, 4, 16>(a, stream) : launch_bwd2_t<io_t, T, GLDS, 4, 12>(a, stream);
-        case 16: return wide ? launch_bwd2_t<io_t, T, GLDS, 16, 16>(a, stream) : launch_bwd2_t<io_t, T, GLDS, 16, 12>(a, stream);
-        default: return hipErrorInvalidValue;
-    }
+static hipError_t launch_bwd2_acc(const BwdArgs& a, hipStream_t stream) {
+    // 13..16 waves: 128-VGPR build; up to 12 waves: 168 VGPRs
+    return a.f.R > 12 ? launch_bwd2_t<io_t, T, GLDS, 16>(a, stream) : launch_bwd2_t<io_t, T, GLDS, 12>(a, stream);
 }
 
 template <typename io_t, bool GLDS>
-static hipError_t launch_bwd2_io(const BwdArgs& a, int T, int nacc, hipStream_t stream) {
+static hipError_t launch_bwd2_io(const BwdArgs& a, int T, hipStream_t stream) {
     switch (T) {
-        case 5: return launch_bwd2_acc<io_t, 5, GLDS>(a, nacc, stream);
-        case 10: return launch_bwd2_acc<io_t, 10, GLDS>(a, nacc, stream);
+        case 5: return launch_bwd2_acc<io_t, 5, GLDS>(a, stream);
+        case 10: return launch_bwd2_acc<io_t, 10, GLDS>(a, stream);
         default: return hipErrorInvalidValue;
     }
 }
 
-hipError_t launch_scan_bwd2(const BwdArgs& a, int dtype, int T, bool glds, int nacc, hipStream_t stream) {
+hipError_t launch_scan_bwd2(const BwdArgs& a, int dtype, int T, bool glds, hipStream_t stream) {
     switch (dtype) {
-        case 0: return glds ? launch_bwd2_io<float, true>(a, T, nacc, stream) : launch_bwd2_io<float, false>(a, T, nacc, stream);
-        case 1: return launch_bwd2_io<f16_t, false>(a, T, nacc, stream);
-        case 2: return launch_bwd2_io<bf16_t, false>(a, T, nacc, stream);
+        case 0: return glds ? launch_bwd2_io<float, true>(a, T, stream) : launch_bwd2_io<float, false>(a, T, stream);
+        case 1: return launch_bwd2_io<f16_t, false>(a, T, stream);
+        case 2: return launch_bwd2_io<bf16_t, false>(a, T, stream);
         default: return hipErrorInvalidValue;
     }
 }

@@ -146,12 +146,13 @@ __device__ __forceinline__ void scan_bwd3_body(const BwdArgs& q, float* smem, in
             const io_t* __restrict__ u_row = reinterpret_cast<const io_t*>(kq->f.u) + (long)b * kq->f.u_bs + (long)ur * kq->f.u_ds;
             const io_t* __restrict__ d_row = reinterpret_cast<const io_t*>(kq->f.delta) + (long)b * kq->f.dt_bs + (long)r * kq->f.dt_ds;
             const io_t* __restrict__ g_row = reinterpret_cast<const io_t*>(kq->dout) + (long)b * kq->g_bs + (long)gr * kq->g_ds;
-            const float bias = kq->f.bias ? kq->f.bias[r] : 0.0f;
+            const int pr = param_row(r, g, rpg, kq->f.pswap);
+            const float bias = kq->f.bias ? kq->f.bias[pr] : 0.0f;
 
             // lane vectors (lane s = state nq0 + s): A[r, :], state entering the tile, reverse carry
             float Av = 0.0f, X0v = 0.0f, Rvv = 0.0f, rvout_v = 0.0f, dA_v = 0.0f;
             if (lane < 4) {
-                Av = kq->f.A[(long)r * kq->f.A_ds + (long)(nq0 + lane) * kq->f.A_ns];
+                Av = kq->f.A[(long)pr * kq->f.A_ds + (long)(nq0 + lane) * kq->f.A_ns];
                 if (j > 0) X0v = kq->f.x[((long)b * kq->f.dim + r) * kq->f.x_rs + (long)(j - 1) * N + nq0 + lane];
                 Rvv = sRv[rl * N + nq0 + lane];
             }
@@ -239,7 +240,7 @@ __device__ __forceinline__ void scan_bwd3_body(const BwdArgs& q, float* smem, in
             cold_args3_t ke = cold_args3();
             if (lane < 4) {
                 sRv[rl * N + nq0 + lane] = rvout_v;
-                atomicAdd(ke->dA + (long)r * ke->dA_ds + (long)(nq0 + lane) * ke->dA_ns, dA_v);
+                atomicAdd(ke->dA + (long)pr * ke->dA_ds + (long)(nq0 + lane) * ke->dA_ns, dA_v);
             }
             // ---- sum over the row's Q waves, then one of them finishes the row
             bool duty = true;
@@ -274,8 +275,8 @@ __device__ __forceinline__ void scan_bwd3_body(const BwdArgs& q, float* smem, in
                 const int ur2 = r - ((g - (g >> ke->f.u_gshift)) * rpg2);
                 const io_t* __restrict__ u_row2 = reinterpret_cast<const io_t*>(ke->f.u) + (long)b * ke->f.u_bs + (long)ur2 * ke->f.u_ds;
                 const io_t* __restrict__ d_row2 = reinterpret_cast<const io_t*>(ke->f.delta) + (long)b * ke->f.dt_bs + (long)r * ke->f.dt_ds;
-                const float Dd = ke->f.D ? ke->f.D[r] : 0.0f;
-                const float bias2 = ke->f.bias ? ke->f.bias[r] : 0.0f;
+                const float Dd = ke->f.D ? ke->f.D[pr] : 0.0f;
+                const float bias2 = ke->f.bias ? ke->f.bias[pr] : 0.0f;
                 float duv[T], ddv[T], dv2[T], uu[T];
                 float dD_acc = 0.0f, dbias_acc = 0.0f;
                 load_items<io_t, T, REV>(d_row2, lbase, L, vec, dv2);
@@ -296,8 +297,8 @@ __device__ __forceinline__ void scan_bwd3_body(const BwdArgs& q, float* smem, in
                 io_t* __restrict__ dd_row = reinterpret_cast<io_t*>(ke->ddelta) + (long)b * ke->dd_bs + (long)r * ke->dd_ds;
                 store_items<io_t, T, REV>(du_row, lbase, L, vec, duv);
                 store_items<io_t, T, REV>(dd_row, lbase, L, vec, ddv);
-                if (ke->dD) { dD_acc = wave_sum(dD_acc); if (lane0) atomicAdd(ke->dD + r, dD_acc); }
-                if (ke->dbias) { dbias_acc = wave_sum(dbias_acc); if (lane0) atomicAdd(ke->dbias + r, dbias_acc); }
+                if (ke->dD) { dD_acc = wave_sum(dD_acc); if (lane0) atomicAdd(ke->dD + pr, dD_acc); }
+                if (ke->dbias) { dbias_acc = wave_sum(dbias_acc); if (lane0) atomicAdd(ke->dbias + pr, dbias_acc); }
             }
         }
 

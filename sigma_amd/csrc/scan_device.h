@@ -474,6 +474,12 @@ struct StagePlan {
 // completion of issue_async() loads of THIS wave; a workgroup barrier must follow before other waves read
 __device__ __forceinline__ void lds_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+// parameter row of channel row r of group g (FwdArgs::pswap): CrossScan direction k = j + 2i is kernel group
+// g = 2j + i, so with pswap the A / D / bias rows of group g are those of group ((g & 1) << 1) | (g >> 1)
+__device__ __forceinline__ int param_row(int r, int g, int rows_per_group, int pswap) {
+    return pswap ? r + ((((g & 1) << 1) | (g >> 1)) - g) * rows_per_group : r;
+}
+
 // ------------------------------------------------------------------ kernel args
 constexpr int kCkptPitch = 1280;   // default elements between state checkpoints in x (see include/sigma_scan.h)
 constexpr int kCkptPitchFine = 640; // fine pitch: one checkpoint per 640-tile, no forward sweep in bwd
@@ -487,6 +493,8 @@ struct FwdArgs {
     int NB;               // states staged per step
     unsigned rev_mask;    // bit g set: group g runs over the sequence in reverse memory order
     int u_gshift;         // u rows of group g are those of group (g >> u_gshift): directions share copies of x
+    int pswap;            // 1: the per-row parameters (A, D, delta_bias and their gradients) of group g live in the
+                          // rows of group swap(g) (middle two of four groups exchanged): reference direction order
     int ckpt_pitch;       // elements between checkpoints (1280 or 640)
     long x_rs;            // floats per row of x: checkpoint j of row (b, r) at x[(b*dim + r)*x_rs + j*N + n]
     long u_bs, u_ds, dt_bs, dt_ds, A_ds, A_ns;

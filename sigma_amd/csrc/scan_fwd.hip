@@ -66,7 +66,12 @@ __device__ __forceinline__ void stage_bc(float* __restrict__ dst, const io_t* __
 
 }  // namespace
 
-template <typename io_t, int T, bool GLDS, bool PREFETCH, bool REV>
+// WSPLIT = false (one tile per workgroup step, W == 1): the state entering the tile is known before the
+// scan, so it is folded into lane 0's in-lane fold and the wave scan runs in the multiplicative form
+// (scan_device.h: no v_exp_f32 per scan step, no exclusive decay product) -- 1 + T instead of 8 + T
+// transcendentals per state and tile.  WSPLIT = true keeps the log-domain scan: the tile aggregates
+// (decay product, end state) of the W waves of a row have to meet in LDS before the incoming state is known.
+template <typename io_t, int T, bool GLDS, bool PREFETCH, bool REV, bool WSPLIT>
 __device__ __forceinline__ void scan_fwd_body(const FwdArgs& p, float* smem, int b, int row0, int g) {
     constexpr int TILE = 64 * T;
     constexpr int VW = vec_width<T>::value;
@@ -92,12 +97,13 @@ __device__ __forceinline__ void scan_fwd_body(const FwdArgs& p, float* smem, int
     io_t* __restrict__ o_row = reinterpret_cast<io_t*>(p.out) + (long)b * p.o_bs + (long)r * p.o_ds;
     const io_t* __restrict__ Bg = reinterpret_cast<const io_t*>(p.B) + (long)b * p.B_bs + (long)g * p.B_gs;
     const io_t* __restrict__ Cg = reinterpret_cast<const io_t*>(p.C) + (long)b * p.C_bs + (long)g * p.C_gs;
-    const float bias = p.bias ? p.bias[r] : 0.0f;
-    const float Dd = p.D ? p.D[r] : 0.0f;
+    const int pr = param_row(r, g, p.rows_per_group, p.pswap);
+    const float bias = p.bias ? p.bias[pr] : 0.0f;
+    const float Dd = p.D ? p.D[pr] : 0.0f;
     float* __restrict__ x_row = p.x ? p.x + ((long)b * p.dim + r) * p.x_rs : nullptr;
 
     if (wt == 0) {
-        const float* __restrict__ A_row = p.A + (long)r * p.A_ds;
+        const float* __restrict__ A_row = p.A + (long)pr * p.A_ds;
         for (int n = lane; n < N; n += 64) {
             sA2[wr * N + n] = A_row[(long)n * p.A_ns] * kLog2e;
             sRun[wr * N + n] = 0.0f;
@@ -117,8 +123,10 @@ __device__ __forceinline__ void scan_fwd_body(const FwdArgs& p, float* smem, int
     auto stage = [&](float* dst, int n0, int tile0) {
         const int nbn = (N - n0 < NB) ? (N - n0) : NB;
         if constexpr (GLDS) {
-            plan.issue(dst, reinterpret_cast<const float*>(Bg), reinterpret_cast<const float*>(Cg), (int)p.B_ns, (int)p.C_ns,
-                       n0, nbn, tile0, L, NB * W * TILE, true);
+            // untracked LDS-DMA (scan_device.h: issue_async): hipcc would drain a builtin global_load_lds at the top of
+            // the block it was meant to overlap with; completion = lds_dma_wait() before the block-end barrier
+            plan.issue_async(dst, reinterpret_cast<const float*>(Bg), reinterpret_cast<const float*>(Cg), (int)p.B_ns,
+                             (int)p.C_ns, n0, nbn, tile0, L, NB * W * TILE);
         } else {
             stage_bc<io_t, T>(dst, Bg, Cg, p.B_ns, p.C_ns, n0, nbn, NB, W, tile0, L, REV, vec);
         }
@@ -128,6 +136,7 @@ __device__ __forceinline__ void scan_fwd_body(const FwdArgs& p, float* smem, int
     float uv[T], dv[T];
     load_items<io_t, T, REV>(u_row, wt * TILE + lane * T, L, vec, uv);
     load_items<io_t, T, REV>(d_row, wt * TILE + lane * T, L, vec, dv);
+    if constexpr (GLDS) lds_dma_wait();
     __syncthreads();
 
     for (int st = 0; st < nsuper; ++st) {
@@ -180,9 +189,10 @@ __device__ __forceinline__ void scan_fwd_body(const FwdArgs& p, float* smem, int
                 const float* tB = cur + (nn * W + wt) * TILE;
                 const float* tC = tB + NB * W * TILE;
 
-                // ---- pass A: lane-local fold with zero incoming state
+                // ---- pass A: lane-local fold (zero incoming state; lane 0 of an unsplit tile starts from the running state)
                 float a[T], bb[T];
-                float xa = 0.0f;
+                float xin = sRunIn[n];
+                float xa = (!WSPLIT && lane == 0) ? xin : 0.0f;
 #pragma unroll
                 for (int q = 0; q < T / VW; ++q) {
                     float bq[VW];
@@ -195,11 +205,16 @@ __device__ __forceinline__ void scan_fwd_body(const FwdArgs& p, float* smem, int
                         xa = fmaf(a[k], xa, bb[k]);
                     }
                 }
-                // ---- wave scan of the lane aggregates (decay product, end state)
-                float sa = A2 * dsum;                   // log2 of the lane's decay product
-                wave_scan_inclusive(sa, xa);
-                float xin = sRunIn[n];
-                if (W > 1) {
+                float x;
+                if constexpr (!WSPLIT) {
+                    // ---- wave scan, multiplicative form; the scanned value IS the state after each lane
+                    float pl = fast_exp2(A2 * dsum);        // the lane's decay product
+                    wave_mscan_inclusive(pl, xa);
+                    x = wave_prev_lane(xa, xin);            // state entering this lane's segment
+                } else {
+                    // ---- wave scan of the lane aggregates (log2 of the decay product, end state)
+                    float sa = A2 * dsum;
+                    wave_scan_inclusive(sa, xa);
                     float2* agg = sAgg + ((n & 1) * R + wr) * W;
                     if (lane == 63) agg[wt] = make_float2(fast_exp2(sa), xa);
                     lds_barrier();
@@ -207,10 +222,10 @@ __device__ __forceinline__ void scan_fwd_body(const FwdArgs& p, float* smem, int
                         const float2 t = agg[w];
                         xin = fmaf(t.x, xin, t.y);
                     }
+                    const float pe = fast_exp2(wave_prev_lane(sa, 0.0f));
+                    const float xe = wave_prev_lane(xa, 0.0f);
+                    x = fmaf(pe, xin, xe);                  // state entering this lane's segment
                 }
-                const float pe = fast_exp2(wave_prev_lane(sa, 0.0f));
-                const float xe = wave_prev_lane(xa, 0.0f);
-                float x = fmaf(pe, xin, xe);            // state entering this lane's segment
 
                 // ---- pass B: replay with the true incoming state, accumulate C.x
 #pragma unroll
@@ -227,6 +242,7 @@ __device__ __forceinline__ void scan_fwd_body(const FwdArgs& p, float* smem, int
                 if (lane == 63 && wt == W - 1) sRunOut[n] = x;    // state after this super-tile
                 if (ckpt) x_row[(long)cidx * N + n] = x;
             }
+            if constexpr (GLDS) lds_dma_wait();
             __syncthreads();                            // staged block landed; current block consumed
         }
         if (!PREFETCH && st + 1 < nsuper) {
@@ -241,7 +257,7 @@ __device__ __forceinline__ void scan_fwd_body(const FwdArgs& p, float* smem, int
 // most 3 waves per SIMD = 12 waves per workgroup; the shorter tiles fit 16 waves.
 template <int T> struct fwd_max_waves { static constexpr int value = (T >= 20) ? 12 : 16; };
 
-template <typename io_t, int T, bool GLDS, bool PREFETCH>
+template <typename io_t, int T, bool GLDS, bool PREFETCH, bool WSPLIT>
 __global__ void __launch_bounds__(64 * fwd_max_waves<T>::value)
 scan_fwd_kernel(const FwdArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -250,15 +266,15 @@ scan_fwd_kernel(const FwdArgs p) {
     const int rb = lb - b * p.rowblocks;
     const int row0 = rb * p.R;
     const int g = row0 / p.rows_per_group;
-    if ((p.rev_mask >> g) & 1u) scan_fwd_body<io_t, T, GLDS, PREFETCH, true>(p, smem, b, row0, g);
-    else scan_fwd_body<io_t, T, GLDS, PREFETCH, false>(p, smem, b, row0, g);
+    if ((p.rev_mask >> g) & 1u) scan_fwd_body<io_t, T, GLDS, PREFETCH, true, WSPLIT>(p, smem, b, row0, g);
+    else scan_fwd_body<io_t, T, GLDS, PREFETCH, false, WSPLIT>(p, smem, b, row0, g);
 }
 
-template <typename io_t, int T, bool GLDS, bool PREFETCH>
-static hipError_t launch_fwd_t(const FwdArgs& a, hipStream_t stream) {
+template <typename io_t, int T, bool GLDS, bool PREFETCH, bool WSPLIT>
+static hipError_t launch_fwd_w(const FwdArgs& a, hipStream_t stream) {
     const size_t lds = fwd_lds_bytes(T, a.R, a.W, a.NB, a.N);
     const int grid = a.rowblocks * a.batch;
-    auto kern = scan_fwd_kernel<io_t, T, GLDS, PREFETCH>;
+    auto kern = scan_fwd_kernel<io_t, T, GLDS, PREFETCH, WSPLIT>;
     // raise the dynamic-LDS cap once per device, kernel and size (not per launch: the call is host-expensive)
     static std::atomic<size_t> lds_cap[kMaxDevices];
     int dev = 0;
@@ -272,6 +288,11 @@ static hipError_t launch_fwd_t(const FwdArgs& a, hipStream_t stream) {
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(a.R * a.W * 64), lds, stream, a);
     return hipGetLastError();
+}
+
+template <typename io_t, int T, bool GLDS, bool PREFETCH>
+static hipError_t launch_fwd_t(const FwdArgs& a, hipStream_t stream) {
+    return a.W > 1 ? launch_fwd_w<io_t, T, GLDS, PREFETCH, true>(a, stream) : launch_fwd_w<io_t, T, GLDS, PREFETCH, false>(a, stream);
 }
 
 template <typename io_t, bool GLDS>

@@ -30,7 +30,8 @@ inline size_t bwd_lds_bytes(int T, int R, int NB, int N, bool slab2 = false) {
 // scan_bwd2: double-buffered B/C stage + nslab slab sets + reverse carries of the chunk's RB*R rows
 inline size_t bwd2_lds_bytes(int T, int R, int NB, int N, bool slab2, int RB) {
     const size_t tile = (size_t)kWave * T;
-    return sizeof(float) * (2 * 2 * (size_t)NB * tile + (slab2 ? 2 : 1) * 2 * (size_t)R * tile + (size_t)RB * R * N + 64);   // + touch sink
+    return sizeof(float) * (2 * 2 * (size_t)NB * tile + (slab2 ? 2 : 1) * 2 * (size_t)R * tile + (size_t)RB * R * N + 64 +   // + touch sink
+                            (RB > 1 ? 2 * (size_t)N * tile : 0));                                                            // + dB/dC accumulators
 }
 
 // scan_bwd3 (state-parallel): B/C of one 320-tile for all states + row partials (two parity sets, reused at
@@ -43,7 +44,7 @@ inline size_t bwd3_lds_bytes(int nw, int N, int RB) {
 
 constexpr int kMaxDevices = 16;    // per-device cache of the raised dynamic-LDS cap (hipFuncSetAttribute is per device)
 
-hipError_t launch_scan_bwd2(const BwdArgs& a, int dtype, int T, bool glds, int nacc, hipStream_t stream);
+hipError_t launch_scan_bwd2(const BwdArgs& a, int dtype, int T, bool glds, hipStream_t stream);
 hipError_t launch_scan_bwd3(const BwdArgs& a, int dtype, bool glds, hipStream_t stream);   // a.f.R = waves per workgroup
 hipError_t launch_reduce_partials(const BwdArgs& a, hipStream_t stream);
 hipError_t bwd2_prof_read(unsigned long long* out16);     // development builds (SIGMA_BWD2_PROF), zeros otherwise

@@ -102,9 +102,10 @@ def _fine_pitch(x, seqlen: int, dstate: int, ckpt_pitch: int) -> int:
 
 
 def _fill_fwd(fp: _capi.FwdParams, u, delta, A, B, C, D_, delta_bias_, out, x, delta_softplus, sizes,
-              rev_mask=0, u_gshift=0, ckpt_pitch=0):
+              rev_mask=0, u_gshift=0, ckpt_pitch=0, param_swap=0):
     batch, dim, seqlen, dstate, n_groups = sizes
     fp.rev_group_mask, fp.u_group_shift = int(rev_mask), int(u_gshift)
+    fp.param_group_swap = int(param_swap)
     if x is not None and x.dim() == 3:              # fine checkpoints: (B, dim, ceil(L/pitch) * N)
         fp.ckpt_pitch, fp.x_row_stride = _fine_pitch(x, seqlen, dstate, ckpt_pitch), x.stride(1)
     fp.batch, fp.dim, fp.seqlen, fp.dstate, fp.n_groups = batch, dim, seqlen, dstate, n_groups
@@ -132,14 +133,17 @@ def fwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B: torch.Tensor, 
 
 
 def fwd_ext(u, delta, A, B, C, D_, delta_bias_, delta_softplus, nrows: int = 1, rev_mask: int = 0,
-            u_gshift: int = 0, need_x: bool = True, fine_ckpt: bool = False, ckpt_pitch: int = 0) -> List[torch.Tensor]:
+            u_gshift: int = 0, need_x: bool = True, fine_ckpt: bool = False, ckpt_pitch: int = 0,
+            param_swap: int = 0) -> List[torch.Tensor]:
     """``fwd`` plus the two extensions of include/sigma_scan.h used by the fused SS2D path:
     ``rev_mask`` (bit g: group g scans backwards, by addressing) and ``u_gshift`` (group g reads
     the u rows of group g >> u_gshift; u has dim >> u_gshift rows).  ``fine_ckpt``: x is allocated
     as (B, dim, ceil(L/640) * N) with one state checkpoint per 640 elements (include/sigma_scan.h),
     which spares ``bwd_ext`` its forward sweep and lets it run the second-generation kernel
     (csrc/scan_bwd2.hip); ``ckpt_pitch`` = 640 / 320 selects the pitch explicitly (320: 320-element
-    backward tiles).  Such an x is only valid for ``bwd_ext``."""
+    backward tiles).  Such an x is only valid for ``bwd_ext``.  ``param_swap`` = 1 (four groups): A, D,
+    delta_bias stay in the reference's direction order while the sequence operands use the kernel's group
+    order (include/sigma_scan.h, param_group_swap)."""
     lib = _capi.load()
     sizes = _check_common(u, delta, A, B, C, D_, delta_bias_, nrows, u_gshift)
     batch, dim, seqlen, dstate, _ = sizes
@@ -157,7 +161,7 @@ def fwd_ext(u, delta, A, B, C, D_, delta_bias_, delta_softplus, nrows: int = 1, 
         return [out, x]
     fp = _capi.FwdParams()
     _fill_fwd(fp, u, delta, A, B, C, D_, delta_bias_, out, x if need_x else None, delta_softplus, sizes,
-              rev_mask, u_gshift, ckpt_pitch)
+              rev_mask, u_gshift, ckpt_pitch, param_swap)
     with torch.cuda.device(u.device):                               # CUDAGuard, :240
         stream = torch.cuda.current_stream(u.device).cuda_stream    # :241
         key = (batch, dim, seqlen, dstate, sizes[4], u.element_size())
@@ -175,7 +179,7 @@ def bwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B: torch.Tensor, 
 
 def bwd_ext(u, delta, A, B, C, D_, delta_bias_, dout, x_, delta_softplus, nrows: int = 1, rev_mask: int = 0,
             u_gshift: int = 0, dout_gshift: int = 0, dB_out: Optional[torch.Tensor] = None,
-            dC_out: Optional[torch.Tensor] = None, ckpt_pitch: int = 0) -> List[Optional[torch.Tensor]]:
+            dC_out: Optional[torch.Tensor] = None, ckpt_pitch: int = 0, param_swap: int = 0) -> List[Optional[torch.Tensor]]:
     """``bwd`` with the extensions of ``fwd_ext``.  du has one row per CHANNEL row (batch, dim, L)
     even when u_gshift folds several groups onto one copy of u; ``dout_gshift`` does the same for
     dout.  ``dB_out`` / ``dC_out``: optional fp32 (B, G, N, L) views (stride(-1) == 1) the kernel
@@ -201,7 +205,9 @@ def bwd_ext(u, delta, A, B, C, D_, delta_bias_, dout, x_, delta_softplus, nrows:
                    "x must have shape (batch_size, dim, n_chunks, 2 * dstate)")
     du = torch.empty_like(delta)                                     # :329-337 (== empty_like(u) in the reference)
     ddelta = torch.empty_like(delta)
-    dA = torch.zeros_like(A)
+    # dA, dD, ddelta_bias are accumulated into (atomicAdd per row and tile): ONE zero fill for all three
+    zeros = torch.zeros(dim * dstate + 2 * dim, dtype=torch.float32, device=A.device)
+    dA = zeros[:dim * dstate].view(dim, dstate)
     # fully written by the library (deterministic two-stage sum), so no zero fill is needed
     if dB_out is not None:
         _check(dB_out.dtype == torch.float32 and tuple(dB_out.shape) == tuple(B.shape) and dB_out.stride(-1) == 1 and
@@ -213,12 +219,12 @@ def bwd_ext(u, delta, A, B, C, D_, delta_bias_, dout, x_, delta_softplus, nrows:
         dC = torch.empty(C.shape, dtype=torch.float32, device=C.device)
     else:
         dB, dC = torch.zeros_like(B, dtype=torch.float32), torch.zeros_like(C, dtype=torch.float32)
-    dD = torch.zeros_like(D_) if D_ is not None else None
-    ddelta_bias = torch.zeros_like(delta_bias_) if delta_bias_ is not None else None
+    dD = zeros[dim * dstate:dim * dstate + dim] if D_ is not None else None
+    ddelta_bias = zeros[dim * dstate + dim:] if delta_bias_ is not None else None
     if batch > 0 and seqlen > 0:
         bp = _capi.BwdParams()
         _fill_fwd(bp.fwd, u, delta, A, B, C, D_, delta_bias_, None, x_, delta_softplus, sizes, rev_mask, u_gshift,
-                  ckpt_pitch)
+                  ckpt_pitch, param_swap)
         bp.dout_group_shift = int(dout_gshift)
         bp.dout, bp.du, bp.ddelta = _ptr(dout), _ptr(du), _ptr(ddelta)
         bp.dA, bp.dB, bp.dC, bp.dD, bp.ddelta_bias = _ptr(dA), _ptr(dB), _ptr(dC), _ptr(dD), _ptr(ddelta_bias)

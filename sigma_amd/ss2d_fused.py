@@ -49,12 +49,19 @@ import os as _os
 _CKPT_ENV = _os.environ.get("SIGMA_CKPT_PITCH", "auto")
 
 
-def ckpt_pitch_for(seqlen: int, dstate: int = 16) -> int:
-    """320-element backward tiles for short sequences (L = 300 pads to 320 instead of 640) and for 4-state
-    scans up to 1280 elements (state-parallel backward, csrc/scan_bwd3.hip); 640 otherwise."""
+def ckpt_pitch_for(seqlen: int, dstate: int = 16, rows: int = 0) -> int:
+    """Checkpoint pitch = backward tile length (include/sigma_scan.h).  Measured on MI355X
+    (profiles/r02_bwd_plans.txt): 320-element tiles win for short sequences (L = 300 pads to 320 instead
+    of 640), for 4-state scans up to 1280 elements (state-parallel backward, csrc/scan_bwd3.hip) and for
+    16-state scans up to 4800 elements when there are enough rows (batch * dim >= 12288) for the
+    row-block loop of csrc/scan_bwd2.hip to run 16-wave workgroups; 640 otherwise."""
     if _CKPT_ENV != "auto":
         return int(_CKPT_ENV)
-    return 320 if (seqlen <= 320 or (dstate <= 4 and seqlen <= 1280)) else 640
+    if seqlen <= 320 or (dstate <= 4 and seqlen <= 1280):
+        return 320
+    if dstate > 8 and seqlen <= 4800 and rows >= 12288:
+        return 320
+    return 640
 
 
 def _two_orders(x4: torch.Tensor) -> torch.Tensor:
@@ -191,7 +198,7 @@ class SelectiveScanExtFn(torch.autograd.Function):
         C = C.float() if C.stride(-1) == 1 else C.float().contiguous()
         A, D, delta_bias = A.float().contiguous(), D.float().contiguous(), delta_bias.float().contiguous()
         out, ck = _core.fwd_ext(u, delta, A, B, C, D, delta_bias, True, rev_mask=rev_mask, u_gshift=u_gshift,
-                                need_x=any(ctx.needs_input_grad), ckpt_pitch=ckpt_pitch_for(u.shape[-1], A.shape[1]))
+                                need_x=any(ctx.needs_input_grad), ckpt_pitch=ckpt_pitch_for(u.shape[-1], A.shape[1], delta.shape[0] * delta.shape[1]))
         ctx.save_for_backward(u, delta, A, B, C, D, delta_bias, ck)
         ctx.ext = (int(rev_mask), int(u_gshift))
         return out
@@ -249,6 +256,17 @@ def cross_split_nhwc(dy: torch.Tensor) -> torch.Tensor:
     return g2
 
 
+def _pair_sum_add(src: torch.Tensor, acc: torch.Tensor, n_outer: int, inner: int) -> None:
+    """acc (n_outer, inner) += src (n_outer, 2, inner).sum(1), one HIP pass (include/sigma_ops.h)."""
+    import ctypes
+    from . import _capi
+    if not (src.is_contiguous() and acc.is_contiguous() and src.dtype == torch.float32 and acc.dtype == torch.float32):
+        raise RuntimeError("pair_sum_add: contiguous fp32 tensors only")
+    with torch.cuda.device(src.device):
+        _capi.check(_capi.load().sigma_pair_sum_add(ctypes.c_void_p(src.data_ptr()), ctypes.c_void_p(acc.data_ptr()), n_outer, inner,
+                                                    ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "pair_sum_add")
+
+
 class SS2DCoreFn(torch.autograd.Function):
     """y = CrossMerge(selective_scan(CrossScan(x), ...)); input xs2 = [row-major, column-major]
     sequences of x, (B, 2, d, H*W) -> y channels-last (B, H, W, d), ready for out_norm."""
@@ -268,13 +286,14 @@ class SS2DCoreFn(torch.autograd.Function):
         p4 = torch.matmul(Wst.unsqueeze(0), xs2).view(B, 4, c, L)              # == (B, group g, R+2N, L)
         dtw = _perm4(dt_projs_weight.float())                                  # (4, d, R)
         delta = torch.matmul(dtw.unsqueeze(0), p4[:, :, :R])                   # (B, 4, d, L)
-        A = _perm4((-torch.exp(A_logs.float())).view(4, d, N)).reshape(4 * d, N)
-        Dp = _perm4(Ds.float().view(4, d)).reshape(-1)
-        bias = _perm4(dt_projs_bias.float()).reshape(-1)
+        # A, D, bias keep the reference's direction order: the kernels map group -> parameter rows (param_swap)
+        A = -torch.exp(A_logs.float())
+        Dp = Ds.float()
+        bias = dt_projs_bias.float().reshape(-1)
         Bv, Cv = p4[:, :, R:R + N], p4[:, :, R + N:]
         need_x = any(ctx.needs_input_grad)
         out, ck = _core.fwd_ext(xs2.view(B, 2 * d, L), delta.view(B, 4 * d, L), A, Bv, Cv, Dp, bias, True,
-                                rev_mask=_REV_MASK, u_gshift=1, need_x=need_x, ckpt_pitch=ckpt_pitch_for(L, N))
+                                rev_mask=_REV_MASK, u_gshift=1, need_x=need_x, ckpt_pitch=ckpt_pitch_for(L, N, B * 4 * d), param_swap=1)
         y = cross_merge_nhwc(out.view(B, 4, d, L), H, W)                       # (B, H, W, d)
         ctx.save_for_backward(xs2, p4, delta, A, Dp, bias, ck, Wst, dtw)
         ctx.dims = (B, d, H, W, c, R, N)
@@ -290,7 +309,7 @@ class SS2DCoreFn(torch.autograd.Function):
         Bv, Cv = p4[:, :, R:R + N], p4[:, :, R + N:]
         du, ddelta, dA, _, _, dD, dbias = _core.bwd_ext(
             xs2.view(B, 2 * d, L), delta.view(B, 4 * d, L), A, Bv, Cv, Dp, bias, g2.view(B, 2 * d, L), ck, True,
-            rev_mask=_REV_MASK, u_gshift=1, dout_gshift=1, dB_out=dp4[:, :, R:R + N], dC_out=dp4[:, :, R + N:])
+            rev_mask=_REV_MASK, u_gshift=1, dout_gshift=1, dB_out=dp4[:, :, R:R + N], dC_out=dp4[:, :, R + N:], param_swap=1)
         ddelta4 = ddelta.view(B, 4, d, L)
         # dt_proj: delta = dtw @ p4[:R]
         dp4[:, :, :R] = torch.matmul(dtw.transpose(1, 2).unsqueeze(0), ddelta4)
@@ -298,15 +317,13 @@ class SS2DCoreFn(torch.autograd.Function):
         # x_proj: p = Wst @ xs2
         dp2 = dp4.view(B, 2, 2 * c, L)
         dxs2 = torch.matmul(Wst.transpose(1, 2).unsqueeze(0), dp2)             # (B, 2, d, L)
-        du4 = du.view(B, 2, 2, d, L)
-        dxs2 += du4[:, :, 0]
-        dxs2 += du4[:, :, 1]
+        _pair_sum_add(du, dxs2, B * 2, d * L)                                  # + du of both directions of an order
         dWst = torch.matmul(dp2, xs2.transpose(-1, -2)).sum(0)                 # (2, 2c, d)
         d_xproj = _perm4(dWst.view(4, c, d))                                   # the permutation is its own inverse
         d_dtw = _perm4(d_dtw)
-        dA_logs = _perm4((dA * A).view(4, d, N)).reshape(4 * d, N)             # A = -exp(A_logs)
-        dDs = _perm4(dD.view(4, d)).reshape(-1)
-        dbias = _perm4(dbias.view(4, d))
+        dA_logs = dA * A                                                       # A = -exp(A_logs); reference order already
+        dDs = dD
+        dbias = dbias.view(4, d)
         return dxs2, None, None, d_xproj, d_dtw, dbias, dA_logs, dDs
 
 

@@ -116,7 +116,8 @@ def check():
         mark("fwd default pitch done")
         g1 = with_opts(dict(bwd_gen=1), lambda: core.bwd_ext(*args, g, x1, True, rev_mask=mask, u_gshift=ush))
         mark("v1 bwd done")
-        variants = [(640, dict(bwd_gen=2)), (640, dict(bwd_gen=2, bwd_rb=2, bwd_slab2=2)), (320, dict(bwd_gen=2)),
+        variants = [(640, dict(bwd_gen=2)), (640, dict(bwd_gen=2, bwd_rb=2, bwd_slab2=2)), (640, dict(bwd_gen=2, bwd_waves=12, bwd_rb=4)),
+                    (320, dict(bwd_gen=2)), (320, dict(bwd_gen=2, bwd_rb=8)),
                     (320, dict(bwd_gen=3)), (320, dict(bwd_gen=3, bwd_waves=12)), (320, dict(bwd_gen=3, bwd_rb=1)),
                     (320, dict(bwd_gen=3, bwd_waves=8, bwd_rb=2))]
         for pitch, opts in variants:
@@ -165,17 +166,12 @@ def bench(names):
             xs[pitch] = core.fwd_ext(u, delta, A, Bm, Cm, D, bias, True, ckpt_pitch=pitch)[1]
         variants = [
             ("v1 fine", 640, dict(bwd_gen=1)),
-            ("v2 T10 R12 rb1", 640, dict(bwd_gen=2, bwd_rb=1)),
-            ("v2 T10 R16 rb1", 640, dict(bwd_gen=2, bwd_waves=16, bwd_rb=1, bwd_nb=2)),
-            ("v2 T10 R16 rb1 slab1", 640, dict(bwd_gen=2, bwd_waves=16, bwd_rb=1, bwd_nb=4, bwd_slab2=2)),
-            ("v3 auto", 320, dict(bwd_gen=3)),
-            ("v3 W12", 320, dict(bwd_gen=3, bwd_waves=12)),
-            ("v3 W8", 320, dict(bwd_gen=3, bwd_waves=8)),
-            ("v3 W16 rb1", 320, dict(bwd_gen=3, bwd_rb=1)),
-            ("v3 W16 rb4", 320, dict(bwd_gen=3, bwd_rb=4)),
-            ("v3 W12 rb4", 320, dict(bwd_gen=3, bwd_waves=12, bwd_rb=4)),
-            ("v2 T5 R8 rb1", 320, dict(bwd_gen=2, bwd_waves=8, bwd_rb=1)),
-            ("v2 T5 R16 rb1", 320, dict(bwd_gen=2, bwd_waves=16, bwd_rb=1)),
+            ("T10 auto", 640, dict()),
+            ("T10 rb1", 640, dict(bwd_rb=1)),
+            ("T10 rb2", 640, dict(bwd_rb=2)),
+            ("T5 auto", 320, dict()),
+            ("T5 rb1", 320, dict(bwd_rb=1, bwd_gen=2)),
+            ("T5 v2 auto", 320, dict(bwd_gen=2)),
         ]
         for label, pitch, opts in variants:
             x = xs[pitch]
