@@ -510,7 +510,7 @@ struct BwdArgs {
     int out_vec_ok;                 // dB/dC rows are 16-byte aligned
     int g_gshift;                   // dout rows of group g are those of group (g >> g_gshift)
     int slab2;                      // two dB/dC slab sets (by state parity): one barrier per state instead of two
-    int flags;                      // bit 0: no L2 warm-up touches (scan_bwd2; option "bwd_notouch")
+    int flags;                      // bit 0: no L2 warm-up touches (scan_bwd2; cleared by option "bwd_touch")
     int RB;                         // scan_bwd2: row blocks (of R rows) a workgroup walks per tile; P = rows_per_group / (R * RB)
     long g_bs, g_ds, du_bs, du_ds, dd_bs, dd_ds, dA_ds, dA_ns;
     long dB_bs, dB_gs, dB_ns, dC_bs, dC_gs, dC_ns;

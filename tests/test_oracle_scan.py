@@ -125,3 +125,30 @@ def test_oracle_linearity_in_u_and_chunk_independence():
         ys.append(torch.stack([(x[0, dd] * Cm[0, dd // rows_per_group, :, l0 + i].double()).sum() for dd in range(Dm)]))
     tail = torch.stack(ys, dim=1).unsqueeze(0).float()
     torch.testing.assert_close(full[..., l0:], tail, rtol=1e-4, atol=1e-4)
+
+
+def test_torch_restatement_of_the_reference_cpu_fallback_matches_the_c_oracle():
+    """oracle/scan_ref_torch.py (the tensor program of selective_scan_interface.py:86-131, timed by
+    bench.py's cpu_baseline) against the C oracle, grouped and 3-D B/C, values and gradients."""
+    import torch
+    from oracle import scan_oracle as so
+    from oracle import scan_ref_torch as rt
+    g = torch.Generator().manual_seed(3)
+    for groups in (0, 2):
+        bsz, dim, L, N = 2, 12, 150, 8
+        u = torch.randn(bsz, dim, L, generator=g)
+        d = 0.5 * torch.rand(bsz, dim, L, generator=g)
+        A = -0.5 * torch.rand(dim, N, generator=g)
+        shp = (bsz, N, L) if groups == 0 else (bsz, groups, N, L)
+        B, C = torch.randn(*shp, generator=g), torch.randn(*shp, generator=g)
+        D, bias = torch.randn(dim, generator=g), 0.5 * torch.rand(dim, generator=g)
+        dout = torch.randn(bsz, dim, L, generator=g)
+        leaves = [t.clone().requires_grad_() for t in (u, d, A, B, C, D, bias)]
+        out = rt.selective_scan_ref(*leaves, True)
+        out.backward(dout)
+        ref = so.selective_scan_oracle(u, d, A, B, C, D, bias, True, acc64=True)
+        torch.testing.assert_close(out.detach(), ref, rtol=1e-4, atol=1e-4)
+        rg = so.selective_scan_oracle_bwd(u, d, A, B if groups else B.unsqueeze(1), C if groups else C.unsqueeze(1), D, bias, dout, True)
+        for t, r in zip(leaves, rg):
+            r = r.reshape(t.shape)
+            torch.testing.assert_close(t.grad, r, rtol=2e-3, atol=1e-3 + 1e-4 * float(r.abs().max()))

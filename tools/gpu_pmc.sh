@@ -8,7 +8,7 @@ mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
 run() {  # name, counters...
   local name=$1; shift
-  timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -o p -- python $R/tools/scan_bench.py --shapes $SHAPES --iters 3 --fine > $OUT/$name.log 2>&1
+  timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$name -o p -- python $R/tools/scan_bench.py --shapes $SHAPES --iters 3 --fine $SCAN_BENCH_ARGS > $OUT/$name.log 2>&1
 }
 if [ "$PASSES" = all ]; then
 run p1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VALU

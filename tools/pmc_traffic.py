@@ -32,8 +32,10 @@ def main():
         for f in glob.glob(os.path.join(d, "p*", "**", "*counter_collection.csv"), recursive=True):
             for r in csv.DictReader(open(f)):
                 if r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
-                    k = "scan_fwd" if "scan_fwd_kernel" in r["Kernel_Name"] else "scan_bwd" if "scan_bwd_kernel" in r["Kernel_Name"] else \
-                        "reduce_partials" if "reduce_partials" in r["Kernel_Name"] else None
+                    kn = r["Kernel_Name"]
+                    k = "scan_fwd" if "scan_fwd_kernel" in kn else \
+                        "scan_bwd" if ("scan_bwd_kernel" in kn or "scan_bwd2_kernel" in kn or "scan_bwd3_kernel" in kn) else \
+                        "reduce_partials" if "reduce_partials" in kn else None
                     if k:
                         vals[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
         B, KD, L, N, G = SHAPES[name]

@@ -88,16 +88,24 @@ def main():
     ap.add_argument("--sweep", action="store_true")
     ap.add_argument("--dtype", default="float32")
     ap.add_argument("--out", default="")
-    ap.add_argument("--fine", action="store_true", help="fine (640) checkpoints, as the fused model path uses")
+    ap.add_argument("--fine", action="store_true", help="one checkpoint per backward tile with the pitch the fused model "
+                    "path picks for the shape (sigma_amd.ss2d_fused.ckpt_pitch_for): the launches of the training step")
+    ap.add_argument("--opt", action="append", default=[], help="library option name=value (sigma_scan_set_option), repeatable")
     a = ap.parse_args()
+    for kv in a.opt:
+        k, v = kv.split("=")
+        _capi.set_option(k, int(v))
     dt = getattr(torch, a.dtype)
     es = 4 if dt == torch.float32 else 2
     rows = []
     for name in a.shapes.split(","):
         shape = SHAPES[name]
         u, delta, A, Bm, Cm, D, bias, dout = make(shape, dt)
+        pitch = 0
         if a.fine:
-            _, x = core.fwd_ext(u, delta, A, Bm, Cm, D, bias, True, fine_ckpt=True)
+            from sigma_amd.ss2d_fused import ckpt_pitch_for
+            pitch = ckpt_pitch_for(shape[2], shape[3], shape[0] * shape[1])
+            _, x = core.fwd_ext(u, delta, A, Bm, Cm, D, bias, True, ckpt_pitch=pitch)
         else:
             _, x = core.fwd(u, delta, A, Bm, Cm, D, bias, True, 1)
         fb, bb = fwd_bytes(*shape, s=es), bwd_bytes(*shape, s=es)
@@ -105,19 +113,19 @@ def main():
         if a.sweep:
             geos += [(t, w, tl) for t in (5, 10, 20) for (w, tl) in ((16, 1), (8, 1), (8, 2), (4, 4), (3, 5), (2, 8), (12, 1))]
         for items, waves, tiles in geos:
-            rec = {"shape": name, "dims": shape, "dtype": a.dtype, "items": items, "waves": waves, "tiles": tiles}
+            rec = {"shape": name, "dims": shape, "dtype": a.dtype, "items": items, "waves": waves, "tiles": tiles, "ckpt_pitch": pitch}
             _capi.set_option("fwd_items", items)
             _capi.set_option("fwd_waves", waves)
             _capi.set_option("fwd_tiles", tiles)
             if a.fine:
-                t = time_call(lambda: core.fwd_ext(u, delta, A, Bm, Cm, D, bias, True, fine_ckpt=True), a.iters)
+                t = time_call(lambda: core.fwd_ext(u, delta, A, Bm, Cm, D, bias, True, ckpt_pitch=pitch), a.iters)
             else:
                 t = time_call(lambda: core.fwd(u, delta, A, Bm, Cm, D, bias, True, 1), a.iters)
             rec.update(fwd_us=t * 1e6, fwd_GBs=fb / t / 1e9, fwd_frac_of_8TBs=fb / t / HBM_PEAK)
             if items in (0, 5, 10) and tiles <= 1:
                 _capi.set_option("bwd_items", items)
                 _capi.set_option("bwd_waves", waves)
-                t = time_call(lambda: core.bwd(u, delta, A, Bm, Cm, D, bias, dout, x, True, 1), max(3, a.iters // 2))
+                t = time_call(lambda: core.bwd_ext(u, delta, A, Bm, Cm, D, bias, dout, x, True, ckpt_pitch=pitch), max(3, a.iters // 2))
                 rec.update(bwd_us=t * 1e6, bwd_GBs=bb / t / 1e9, bwd_frac_of_8TBs=bb / t / HBM_PEAK)
             for k in ("fwd_items", "fwd_waves", "fwd_tiles", "bwd_items", "bwd_waves"):
                 _capi.set_option(k, 0)
