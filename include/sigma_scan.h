@@ -71,6 +71,7 @@ enum sigma_status {
 #define SIGMA_SCAN_CHUNK 2048
 #define SIGMA_SCAN_CKPT_PITCH 1280
 #define SIGMA_SCAN_CKPT_PITCH_FINE 640
+#define SIGMA_SCAN_CKPT_PITCH_160 160
 #define SIGMA_SCAN_CKPT_PITCH_320 320
 /* dstate limit of the reference (selective_scan.cpp:10,201). */
 #define SIGMA_SCAN_MAX_DSTATE 256

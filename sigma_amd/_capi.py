@@ -19,6 +19,7 @@ SIGMA_SCAN_CHUNK = 2048
 SIGMA_SCAN_CKPT_PITCH = 1280
 SIGMA_SCAN_CKPT_PITCH_FINE = 640
 SIGMA_SCAN_CKPT_PITCH_320 = 320
+SIGMA_SCAN_CKPT_PITCH_160 = 160
 SIGMA_SCAN_MAX_DSTATE = 256
 
 DTYPE_F32, DTYPE_F16, DTYPE_BF16 = 0, 1, 2

@@ -20,7 +20,7 @@ thread_local std::string g_err;
 
 std::atomic<int> g_opt_fwd_items{0}, g_opt_fwd_waves{0}, g_opt_fwd_tiles{0}, g_opt_fwd_nb{0};
 std::atomic<int> g_opt_bwd_items{0}, g_opt_bwd_waves{0}, g_opt_bwd_nb{0}, g_opt_no_glds{0}, g_opt_bwd_slab2{0}, g_opt_fwd_prefetch{0};
-std::atomic<int> g_opt_bwd_gen{0}, g_opt_bwd_rb{0}, g_opt_bwd_touch{0};
+std::atomic<int> g_opt_bwd_gen{0}, g_opt_bwd_rb{0}, g_opt_bwd_touch{0}, g_opt_bwd_sb{0};
 
 int fail(int code, const char* fmt, ...) {
     char buf[512];
@@ -54,9 +54,9 @@ int check_fwd(const sigma_scan_fwd_params* p, bool need_out, bool need_ptrs = tr
     if (p->rev_group_mask != 0 && (p->n_groups > 32 || (p->n_groups < 32 && (p->rev_group_mask >> p->n_groups) != 0)))
         return fail(SIGMA_ERR_BAD_SHAPE, "rev_group_mask 0x%x names groups >= n_groups (%d)", p->rev_group_mask, p->n_groups);
     if (p->ckpt_pitch != 0 && p->ckpt_pitch != SIGMA_SCAN_CKPT_PITCH && p->ckpt_pitch != SIGMA_SCAN_CKPT_PITCH_FINE &&
-        p->ckpt_pitch != SIGMA_SCAN_CKPT_PITCH_320)
-        return fail(SIGMA_ERR_BAD_SHAPE, "ckpt_pitch must be 0, %d, %d or %d (got %d)", SIGMA_SCAN_CKPT_PITCH,
-                    SIGMA_SCAN_CKPT_PITCH_FINE, SIGMA_SCAN_CKPT_PITCH_320, p->ckpt_pitch);
+        p->ckpt_pitch != SIGMA_SCAN_CKPT_PITCH_320 && p->ckpt_pitch != SIGMA_SCAN_CKPT_PITCH_160)
+        return fail(SIGMA_ERR_BAD_SHAPE, "ckpt_pitch must be 0, %d, %d, %d or %d (got %d)", SIGMA_SCAN_CKPT_PITCH,
+                    SIGMA_SCAN_CKPT_PITCH_FINE, SIGMA_SCAN_CKPT_PITCH_320, SIGMA_SCAN_CKPT_PITCH_160, p->ckpt_pitch);
     {
         const int pitch = p->ckpt_pitch ? p->ckpt_pitch : SIGMA_SCAN_CKPT_PITCH;
         const int64_t need = (int64_t)((p->seqlen + pitch - 1) / pitch) * p->dstate;
@@ -361,6 +361,53 @@ Plan3 plan_bwd3(const sigma_scan_fwd_params* p, bool vec) {
     return pl;
 }
 
+// scan_bwd4 (scan_bwd4.hip): quad-row mapping, 160-position tiles; a workgroup is W waves x 4 rows and walks RB
+// row blocks per tile; P = rows_per_group / (4 * W * RB) workgroups share a group; SB states share a barrier.
+struct Plan4 { bool ok; int W, RB, SB, P, grid; size_t lds; };
+
+Plan4 plan_bwd4(const sigma_scan_fwd_params* p, bool vec) {
+    Plan4 pl;
+    std::memset(&pl, 0, sizeof(pl));
+    if (p->ckpt_pitch != SIGMA_SCAN_CKPT_PITCH_160) return pl;
+    const int N = p->dstate;
+    if (N != 2 && N != 4 && N != 8 && N != 16) return pl;
+    if (!glds_ok(p, vec)) return pl;                                  // f32, aligned B/C: the kernel stages by LDS-DMA only
+    const int rpg = p->dim / p->n_groups;
+    if (rpg % 4 != 0) return pl;
+    const int quads = rpg / 4;                                       // wave-sized row quads per group
+    const int fr = g_opt_bwd_waves.load();
+    // workgroups wanted: one per CU at least; fewer waves per workgroup when the problem has few rows
+    int W = 0;
+    if (fr > 0 && fr <= 12 && quads % fr == 0) W = fr;
+    for (int w = 12; W == 0 && w >= 1; --w) {
+        if (quads % w != 0) continue;
+        if ((long)p->batch * p->n_groups * (quads / w) >= kCUs || w <= 4) W = w;
+    }
+    if (W == 0) return pl;
+    const int rowblocks = quads / W;
+    int RB = 1;
+    const int frb = g_opt_bwd_rb.load();
+    if (frb > 0) {
+        RB = frb;
+        while (RB > 1 && rowblocks % RB != 0) --RB;
+    } else {
+        for (int d = 1; d <= rowblocks; ++d)
+            if (rowblocks % d == 0 && (long)p->batch * p->n_groups * (rowblocks / d) >= kCUs) RB = d;
+    }
+    int SB = g_opt_bwd_sb.load() > 0 ? g_opt_bwd_sb.load() : 2;
+    while (SB > 1 && N % SB != 0) SB >>= 1;
+    while (sigma::bwd4_lds_bytes(W, N, SB, RB) > kLdsLimit) {
+        if (SB > 1) SB >>= 1;
+        else if (RB > 1) { --RB; while (RB > 1 && rowblocks % RB != 0) --RB; }
+        else return pl;
+    }
+    pl.ok = true;
+    pl.W = W; pl.RB = RB; pl.SB = SB; pl.P = rowblocks / RB;
+    pl.grid = p->batch * p->n_groups * pl.P;
+    pl.lds = sigma::bwd4_lds_bytes(W, N, SB, RB);
+    return pl;
+}
+
 }  // namespace
 
 extern "C" {
@@ -383,6 +430,7 @@ OptDesc g_opts[] = {
     {"bwd_slab2", &g_opt_bwd_slab2, {0, 1, 2, -1}},        // 1 = two dB/dC slab sets when they fit
     {"fwd_prefetch", &g_opt_fwd_prefetch, {0, 1, 2, -1}},  // 2 = no register prefetch of the next tile's u/delta (T = 10)
     {"bwd_gen", &g_opt_bwd_gen, {0, 1, 2, 3, -1}},         // backward kernel: 1 = scan_bwd.hip, 2 = scan_bwd2.hip, 3 / 0 = best legal
+    {"bwd_sb", &g_opt_bwd_sb, {0, 1, 2, 4, 8, -1}},          // quad-row backward: states per barrier (0 = 2)
     {"bwd_touch", &g_opt_bwd_touch, {0, 1, -1}},   // 1 = L2 warm-up touches of the next row step (doubles FETCH_SIZE, ~1% faster)
     {"bwd_rb", &g_opt_bwd_rb, {-3}},                       // scan_bwd2: row blocks per workgroup, 0..256
 };
@@ -423,6 +471,13 @@ int sigma_scan_bwd_plan(const sigma_scan_bwd_params* p, int32_t plan[6]) {
     int rc = check_fwd(&p->fwd, false, false);
     if (rc) return rc;
     if (!plan) return fail(SIGMA_ERR_NULL_ARG, "plan is NULL");
+    if (p->fwd.ckpt_pitch == SIGMA_SCAN_CKPT_PITCH_160) {
+        const Plan4 p4 = plan_bwd4(&p->fwd, true);
+        if (!p4.ok) return fail(SIGMA_ERR_BAD_SHAPE, "ckpt_pitch 160 (quad-row backward) is not available for this problem");
+        // items = 10, rows slot = waves (4 rows each), states_per_block slot = -(100 + states per barrier)
+        plan[0] = 10; plan[1] = p4.W; plan[2] = p4.grid; plan[3] = (int32_t)p4.lds; plan[4] = -p4.RB; plan[5] = -(100 + p4.SB);
+        return SIGMA_OK;
+    }
     const Plan3 p3 = plan_bwd3(&p->fwd, true);
     if (p3.ok) {       // items = 5, states_per_block slot = -(waves per row) marks the state-parallel kernel
         plan[0] = 5; plan[1] = p3.nw; plan[2] = p3.grid; plan[3] = (int32_t)p3.lds; plan[4] = -p3.RB; plan[5] = -(p->fwd.dstate / 4);
@@ -468,6 +523,11 @@ int64_t sigma_scan_bwd_workspace_bytes(const sigma_scan_bwd_params* q) {
     const sigma_scan_fwd_params* p = &q->fwd;
     if (check_fwd(p, false, false)) return -1;
     if (p->batch == 0 || p->seqlen == 0) return 0;
+    if (p->ckpt_pitch == SIGMA_SCAN_CKPT_PITCH_160) {
+        const Plan4 p4 = plan_bwd4(p, true);
+        if (!p4.ok) { fail(SIGMA_ERR_BAD_SHAPE, "ckpt_pitch 160 (quad-row backward) is not available for this problem"); return -1; }
+        return p4.P <= 1 ? 0 : (int64_t)2 * p4.P * p->batch * p->n_groups * (int64_t)p->dstate * p->seqlen * (int64_t)sizeof(float);
+    }
     const Plan3 p3 = plan_bwd3(p, true);     // no plan's workgroup count depends on alignment
     if (p3.ok)
         return p3.P <= 1 ? 0 : (int64_t)2 * p3.P * p->batch * p->n_groups * (int64_t)p->dstate * p->seqlen * (int64_t)sizeof(float);
@@ -493,18 +553,27 @@ int sigma_selective_scan_bwd(const sigma_scan_bwd_params* q, void* stream) {
     if ((p->D == nullptr) != (q->dD == nullptr) || (p->delta_bias == nullptr) != (q->ddelta_bias == nullptr))
         return fail(SIGMA_ERR_NULL_ARG, "dD / ddelta_bias must be given exactly when D / delta_bias are");
     const bool vec = vec_ok_bwd(q);
-    const Plan3 p3 = plan_bwd3(p, vec);
+    Plan4 p4;
+    std::memset(&p4, 0, sizeof(p4));
+    if (p->ckpt_pitch == SIGMA_SCAN_CKPT_PITCH_160) {
+        // B/C alignment is part of the plan: the caller chose the pitch at forward time with the same tensors
+        p4 = plan_bwd4(p, vec_ok_fwd(p, false));
+        if (!p4.ok)
+            return fail(SIGMA_ERR_BAD_SHAPE, "ckpt_pitch 160 needs f32 IO, 16-byte aligned B/C, dstate in {2,4,8,16} and rows per group divisible by 4");
+    }
+    const Plan3 p3 = p4.ok ? Plan3{} : plan_bwd3(p, vec);
     Plan2 p2;
     std::memset(&p2, 0, sizeof(p2));
-    if (!p3.ok) p2 = plan_bwd2(p, vec);
+    if (!p3.ok && !p4.ok) p2 = plan_bwd2(p, vec);
     Plan pl;
-    if (p3.ok) { pl.items = 5; pl.rows = p3.nw; pl.tiles = 1; pl.nb = p->dstate; pl.grid = p3.grid; pl.glds = p3.glds; pl.lds = p3.lds; pl.slab2 = false; }
+    if (p4.ok) { pl.items = 10; pl.rows = p4.W; pl.tiles = 1; pl.nb = p->dstate; pl.grid = p4.grid; pl.glds = true; pl.lds = p4.lds; pl.slab2 = false; }
+    else if (p3.ok) { pl.items = 5; pl.rows = p3.nw; pl.tiles = 1; pl.nb = p->dstate; pl.grid = p3.grid; pl.glds = p3.glds; pl.lds = p3.lds; pl.slab2 = false; }
     else if (p2.ok) { pl.items = p2.items; pl.rows = p2.rows; pl.tiles = 1; pl.nb = p2.nb; pl.grid = p2.grid; pl.glds = p2.glds; pl.lds = p2.lds; pl.slab2 = p2.slab2; }
     else pl = plan_bwd(p, vec);
     if (!p2.ok && !p3.ok && p->ckpt_pitch == SIGMA_SCAN_CKPT_PITCH_320 && g_opt_bwd_gen.load() == 1)
         return fail(SIGMA_ERR_BAD_OPTION, "ckpt_pitch 320 needs the second-generation backward (option bwd_gen != 1)");
     if (pl.lds > kLdsLimit) return fail(SIGMA_ERR_BAD_SHAPE, "LDS budget exceeded (%zu B)", pl.lds);
-    const int P = p3.ok ? p3.P : (p2.ok ? p2.P : (p->dim / p->n_groups) / pl.rows);
+    const int P = p4.ok ? p4.P : p3.ok ? p3.P : (p2.ok ? p2.P : (p->dim / p->n_groups) / pl.rows);
     const int64_t slab = (int64_t)P * p->batch * p->n_groups * (int64_t)p->dstate * p->seqlen;
     if (P > 1) {
         if (!q->workspace || q->workspace_bytes < 2 * slab * (int64_t)sizeof(float))
@@ -534,8 +603,9 @@ int sigma_selective_scan_bwd(const sigma_scan_bwd_params* q, void* stream) {
     a.ws_dB = P > 1 ? static_cast<float*>(q->workspace) : nullptr;
     a.ws_dC = P > 1 ? static_cast<float*>(q->workspace) + slab : nullptr;
     a.flags = g_opt_bwd_touch.load() ? 0 : 1;
-    a.RB = p3.ok ? p3.RB : (p2.ok ? p2.RB : 1);
-    hipError_t e = p3.ok ? sigma::launch_scan_bwd3(a, p->io_dtype, pl.glds, static_cast<hipStream_t>(stream)) : p2.ok ? sigma::launch_scan_bwd2(a, p->io_dtype, pl.items, pl.glds, static_cast<hipStream_t>(stream))
+    a.RB = p4.ok ? p4.RB : p3.ok ? p3.RB : (p2.ok ? p2.RB : 1);
+    if (p4.ok) a.slab2 = p4.SB;
+    hipError_t e = p4.ok ? sigma::launch_scan_bwd4(a, static_cast<hipStream_t>(stream)) : p3.ok ? sigma::launch_scan_bwd3(a, p->io_dtype, pl.glds, static_cast<hipStream_t>(stream)) : p2.ok ? sigma::launch_scan_bwd2(a, p->io_dtype, pl.items, pl.glds, static_cast<hipStream_t>(stream))
                          : sigma::launch_scan_bwd(a, p->io_dtype, pl.items, pl.glds, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(SIGMA_ERR_LAUNCH, "scan_bwd launch failed: %s", hipGetErrorString(e));
     return SIGMA_OK;

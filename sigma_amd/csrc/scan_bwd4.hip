@@ -1,0 +1,483 @@
+// scan_bwd4.hip -- selective-scan backward, "quad-row" mapping (gfx950 / MI355X, wave64, f32 IO).
+//
+// Same operator as scan_bwd2.hip (reference: models/encoders/selective_scan/csrc/selective_scan/
+// selective_scan_bwd_kernel.cuh:66-308, reverse_scan.cuh:18-401; mathematics SURVEY.md App. E.2), other
+// mapping of rows to lanes.  The round-2 counters of scan_bwd2 (profiles/r02_pmc_enc_s2_b16.txt) show a
+// kernel bound by VALU issue plus LDS traffic, both dominated by overheads of the 64-lane tile:
+//   * two 6-step wave scans per state and T elements (32 DPP instructions incl. the cross-row steps),
+//   * 8 bytes of LDS written and 8 read per element-state for the dB/dC row reduction (every wave hands its
+//     row's terms to the column-sum threads), the column sums themselves, one barrier per state.
+// Here a wave is FOUR rows x 16 lanes x T = 10 positions (tile = 160 positions, one DPP row per channel row):
+//   * the scans stay inside a DPP row: 4 steps (row_shr / row_shl), no row_bcast / readlane fix-ups;
+//   * the dB/dC terms of the wave's four rows are summed IN REGISTERS with the gfx950 lane-swap instructions
+//     (v_permlane32_swap: upper half of one register <-> lower half of another; v_permlane16_swap: odd DPP
+//     rows <-> even DPP rows; semantics pinned by tools/ubench/lane_ops_probe.hip): 20 registers of per-row
+//     terms become 5 registers of four-row sums in which every lane carries a distinct column, so a wave
+//     writes 5 dwords per lane and state instead of 20, and the column sums read a quarter as much;
+//   * the slabs are small (W x 320 floats per state), so several states share one barrier ("SB");
+//   * the B/C image of a tile (all N states, 2*N*160 floats) is staged once per tile for all row blocks of
+//     the workgroup, by LDS-DMA, while the previous tile is being processed;
+//   * per-row scalars of a state (A, checkpoint, reverse carry) live in lane vectors (lane 16*row + n) and
+//     are broadcast inside their DPP row with ds_bpermute_b32; the per-state results (outgoing carry, dA)
+//     are collected with a select + row rotate.
+// Needs: f32 IO, B/C eligible for global_load_lds, dstate in {2,4,8,16}, ckpt_pitch 160, rows per group
+// divisible by 4*W.  Everything else stays on scan_bwd2.hip / scan_bwd.hip.
+#include "scan_device.h"
+#include "scan_launch.h"
+
+#include <atomic>
+
+namespace sigma {
+namespace {
+
+constexpr int kT4 = 10;            // positions per lane
+constexpr int kTile4 = 160;        // positions per DPP row and tile
+constexpr int kCols4 = 320;        // dB + dC columns of a tile = 5 registers x 64 lanes per wave and state
+
+typedef const __attribute__((address_space(4))) BwdArgs* cold4_t;   // kernarg segment: s_load (see scan_bwd2.hip)
+__device__ __forceinline__ cold4_t cold_args4() {
+    cold4_t kp = (cold4_t)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));
+    return kp;
+}
+
+// LDS-DMA staging of one tile: image [arr = B, C][N][160] floats in memory order, in units of 64 chunks of
+// 16 bytes (wave v issues units v, v + nwaves, ...).  Issued once per tile and wave, so the chunk -> (state,
+// offset) decomposition is simply recomputed.  Untracked issue (see StagePlan::issue_async in scan_device.h):
+// the caller retires it with lds_dma_wait() + a barrier.
+template <bool REV>
+__device__ __forceinline__ void stage_tile4(float* dst, const float* Bg, const float* Cg, int B_ns, int C_ns, int N,
+                                            int tile, int L) {
+    constexpr int CPR = kTile4 / 4;                // 16-byte chunks per (state, tile)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwaves = blockDim.x >> 6;
+    const int total = N * CPR;
+    const int units = (total + 63) / 64;
+    const int t0 = REV ? (L - kTile4 - tile * kTile4) : tile * kTile4;     // memory index of image element 0
+    for (int unit = wave; unit < units; unit += nwaves) {
+        const int ci = unit * 64 + lane;
+        const int n = ci / CPR;
+        const int m = t0 + (ci - n * CPR) * 4;
+        const bool ok = ci < total && m >= 0 && m < L;                     // L % 4 == 0: whole chunk in range
+        const unsigned ldsB = (unsigned)(uintptr_t)(lptr_t)(dst + unit * 256);
+        const unsigned ldsC = ldsB + (unsigned)(N * kTile4) * 4u;
+        if (ok) {
+            const char* gb = reinterpret_cast<const char*>(Bg) + (unsigned)(n * B_ns + m) * 4u;
+            const char* gc = reinterpret_cast<const char*>(Cg) + (unsigned)(n * C_ns + m) * 4u;
+            unsigned keep;
+            asm volatile(
+                "s_mov_b32 %0, m0\n\t"
+                "s_mov_b32 m0, %3\n\t"
+                "s_nop 0\n\t"
+                "global_load_lds_dwordx4 %1, off\n\t"
+                "s_mov_b32 m0, %4\n\t"
+                "s_nop 0\n\t"
+                "global_load_lds_dwordx4 %2, off\n\t"
+                "s_mov_b32 m0, %0"
+                : "=&s"(keep) : "v"(gb), "v"(gc), "s"(ldsB), "s"(ldsC) : "memory");
+        }
+    }
+}
+
+// positions 2q, 2q+1 of the lane's 10 (li = lane inside its DPP row); the image is in memory order
+template <bool REV>
+__device__ __forceinline__ void lds_read_pair(const float* __restrict__ tile, int li, int q, float (&v)[2]) {
+    const float* __restrict__ src = REV ? tile + (15 - li) * kT4 + (kT4 - (q + 1) * 2) : tile + li * kT4 + q * 2;
+    const float2 x = *reinterpret_cast<const float2*>(src);
+    v[0] = REV ? x.y : x.x;
+    v[1] = REV ? x.x : x.y;
+}
+
+// ---- scans inside one DPP row (16 lanes): the first four steps of wave_mscan_inclusive{,_rev}
+#define SIGMA_MSTEP(CTRL)                                          \
+    "v_fmac_f32_dpp %1, %1, %0 " CTRL "\n\t"                       \
+    "v_mul_f32_dpp %0, %0, %0 " CTRL "\n\t"                        \
+    "s_nop 0\n\t"
+#define SIGMA_MSTEP_LAST(CTRL)                                     \
+    "v_fmac_f32_dpp %1, %1, %0 " CTRL "\n\t"
+__device__ __forceinline__ void row_mscan_inclusive(float& p, float& x) {          // lane 0 of the row earliest
+    asm volatile(
+        "s_nop 1\n\t"
+        SIGMA_MSTEP("row_shr:1 row_mask:0xf bank_mask:0xf")
+        SIGMA_MSTEP("row_shr:2 row_mask:0xf bank_mask:0xf")
+        SIGMA_MSTEP("row_shr:4 row_mask:0xf bank_mask:0xf")
+        SIGMA_MSTEP_LAST("row_shr:8 row_mask:0xf bank_mask:0xf")
+        "s_nop 1\n\t"
+        : "+v"(p), "+v"(x));
+}
+__device__ __forceinline__ void row_mscan_inclusive_rev(float& p, float& x) {      // lane 15 of the row earliest
+    asm volatile(
+        "s_nop 1\n\t"
+        SIGMA_MSTEP("row_shl:1 row_mask:0xf bank_mask:0xf")
+        SIGMA_MSTEP("row_shl:2 row_mask:0xf bank_mask:0xf")
+        SIGMA_MSTEP("row_shl:4 row_mask:0xf bank_mask:0xf")
+        SIGMA_MSTEP_LAST("row_shl:8 row_mask:0xf bank_mask:0xf")
+        "s_nop 1\n\t"
+        : "+v"(p), "+v"(x));
+}
+#undef SIGMA_MSTEP
+#undef SIGMA_MSTEP_LAST
+
+// sum over the 16 lanes of a DPP row, total in lane 0 of the row (other lanes: partial sums)
+__device__ __forceinline__ float row_sum_to_lane0(float v) {
+    v += dpp_take<DPP_ROW_SHL1, 0xF>(0.0f, v);
+    v += dpp_take<DPP_ROW_SHL2, 0xF>(0.0f, v);
+    v += dpp_take<DPP_ROW_SHL4, 0xF>(0.0f, v);
+    v += dpp_take<DPP_ROW_SHL8, 0xF>(0.0f, v);
+    return v;
+}
+// lane i of a row <- lane i+1 (lane 15 <- lane 0): row_ror:15
+__device__ __forceinline__ float row_rotate_left(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x12F, 0xF, 0xF, false));
+}
+// every lane <- lane (16*row + n) of its own DPP row (n wave-uniform)
+__device__ __forceinline__ float row_pick(float v, int addr4) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(addr4, __builtin_bit_cast(int, v)));
+}
+
+// a + b with the halves / rows regrouped (tools/ubench/lane_ops_probe.hip):
+//   swap32: lanes 0-31 of the result = a[0:32] + a[32:64], lanes 32-63 = b[0:32] + b[32:64]
+//   swap16: DPP rows of the result = {a.r0 + a.r1, b.r0 + b.r1, a.r2 + a.r3, b.r2 + b.r3}
+__device__ __forceinline__ float fold32(float a, float b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+    return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+__device__ __forceinline__ float fold16(float a, float b) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+    return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+
+// sum of one column over the W wave slabs, fixed order, reads batched ahead of the adds
+template <int RR>
+__device__ __forceinline__ float colsum1_fixed(const float* __restrict__ colp, int stride) {
+    float v[RR];
+#pragma unroll
+    for (int w = 0; w < RR; ++w) v[w] = colp[w * stride];
+    float s = 0.0f;
+#pragma unroll
+    for (int w = 0; w < RR; ++w) s += v[w];
+    return s;
+}
+__device__ __forceinline__ float colsum1(const float* __restrict__ colp, int stride, int W) {
+    float s = 0.0f;
+    int w = 0;
+    for (; w + 12 <= W; w += 12) s += colsum1_fixed<12>(colp + w * stride, stride);
+    if (w + 8 <= W) { s += colsum1_fixed<8>(colp + w * stride, stride); w += 8; }
+    if (w + 4 <= W) { s += colsum1_fixed<4>(colp + w * stride, stride); w += 4; }
+    for (; w < W; ++w) s += colp[w * stride];
+    return s;
+}
+
+}  // namespace
+
+template <bool REV>
+__device__ __forceinline__ void scan_bwd4_body(const BwdArgs& q, float* smem, int b, int g, int chunk) {
+    constexpr int T = kT4;
+    const FwdArgs& p = q.f;
+    const int W = blockDim.x >> 6;                    // waves; 4 rows each
+    const int N = p.N, L = p.L, RB = q.RB;
+    const int SB = q.slab2;                           // states per barrier; 2*SB slab sets
+    const int bufsz = 2 * N * kTile4;
+    float* sBC = smem;                                // [2][2][N][160]
+    float* sRed = sBC + 2 * bufsz;                    // [2*SB][W][320] four-row sums of the dB/dC terms
+    float* sRv = sRed + 2 * SB * W * kCols4;          // [RB*4*W][N] reverse carry a*dx of the tile to the right
+    float* sAcc = sRv + RB * 4 * W * N;               // [N][320] when RB > 1
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int li = lane & 15;
+    const int qr = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool vec = p.vec_ok != 0;
+    const bool li0 = li == 0, li15 = li == 15;
+    const int row_c0 = g * p.rows_per_group + chunk * RB * 4 * W;   // first row of this workgroup's chunk
+    const int rowbase4 = (lane & 48) << 2;            // ds_bpermute byte address of lane 0 of this DPP row
+    const int vshift = 16 - N;                        // collected lane vectors: state n sits in lane vshift + n
+
+    const float* __restrict__ Bg = reinterpret_cast<const float*>(p.B) + (long)b * p.B_bs + (long)g * p.B_gs;
+    const float* __restrict__ Cg = reinterpret_cast<const float*>(p.C) + (long)b * p.C_bs + (long)g * p.C_gs;
+    float* __restrict__ oB;
+    float* __restrict__ oC;
+    long o_nsB, o_nsC;
+    if (q.P == 1) {
+        oB = q.dB + (long)b * q.dB_bs + (long)g * q.dB_gs; o_nsB = q.dB_ns;
+        oC = q.dC + (long)b * q.dC_bs + (long)g * q.dC_gs; o_nsC = q.dC_ns;
+    } else {
+        const long slab = (((long)chunk * p.batch + b) * p.G + g) * (long)N * L;
+        oB = q.ws_dB + slab; oC = q.ws_dC + slab; o_nsB = L; o_nsC = L;
+    }
+
+    for (int i = tid; i < RB * 4 * W * N; i += blockDim.x) sRv[i] = 0.0f;
+    // never multiply uninitialised LDS bits (stale/NaN) into the padding of the last tile
+    for (int i = tid; i < 2 * bufsz / 4; i += blockDim.x) reinterpret_cast<float4*>(sBC)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+
+    const int ntiles = (L + kTile4 - 1) / kTile4;
+    auto stage = [&](int buf, int tile) {
+        stage_tile4<REV>(sBC + buf * bufsz, Bg, Cg, (int)p.B_ns, (int)p.C_ns, N, tile, L);
+    };
+
+    // column c of a state's 320: register m = c / 64 of lane c % 64: DPP row rr = (c % 64) / 16 holds
+    // {dB pos 2m, dB pos 2m+1, dC pos 2m, dC pos 2m+1}[rr] of the 10 positions of lane (c % 16) -- see fold16.
+    // Column-sum threads: with S = threads / 320 >= 1, thread t < 320*S owns column t % 320 of the states
+    // t / 320, t / 320 + S, ... of a state group (its position inside the tile is computed once); smaller
+    // workgroups loop over the columns as well.
+    const int colS = (int)blockDim.x / kCols4;
+    const int col_c = tid % kCols4;
+    const int col_s0 = tid / kCols4;
+    auto col_pos = [&](int c, bool& is_c) {
+        const int m = c >> 6, cl = c & 63, rr = cl >> 4, cli = cl & 15;
+        is_c = rr >= 2;
+        return cli * T + 2 * m + (rr & 1);
+    };
+    bool my_is_c;
+    const int my_pos = col_pos(col_c, my_is_c);
+    auto put_at = [&](int n, int l0, int pos, bool is_c, float v) {
+        const int sp = l0 + pos;                                      // scan position
+        if (sp < L) {
+            const int mi = REV ? (L - 1 - sp) : sp;
+            float* __restrict__ dst = is_c ? oC + (long)n * o_nsC : oB + (long)n * o_nsB;
+            dst[mi] = v;
+        }
+    };
+
+    int buf = 0;
+    int grp = 0;                                       // state groups processed (slab set parity)
+    stage(0, ntiles - 1);
+    lds_dma_wait();
+    __syncthreads();
+
+    for (int j = ntiles - 1; j >= 0; --j) {
+        const int l0 = j * kTile4;
+        const int lbase = l0 + li * T;
+        const float* cur = sBC + buf * bufsz;
+        if (j > 0) stage(buf ^ 1, j - 1);              // lands while this tile is processed
+        for (int rb = 0; rb < RB; ++rb) {
+            const int rl = (rb * W + wave) * 4 + qr;   // row inside the chunk (per DPP row)
+            const int r = row_c0 + rl;
+            cold4_t kq = cold_args4();
+            const int rpg = kq->f.rows_per_group;
+            const int ur = r - ((g - (g >> kq->f.u_gshift)) * rpg);   // same row of group g >> u_gshift
+            const int gr = r - ((g - (g >> kq->g_gshift)) * rpg);
+            const float* __restrict__ u_row = reinterpret_cast<const float*>(kq->f.u) + (long)b * kq->f.u_bs + (long)ur * kq->f.u_ds;
+            const float* __restrict__ d_row = reinterpret_cast<const float*>(kq->f.delta) + (long)b * kq->f.dt_bs + (long)r * kq->f.dt_ds;
+            const float* __restrict__ g_row = reinterpret_cast<const float*>(kq->dout) + (long)b * kq->g_bs + (long)gr * kq->g_ds;
+            const int pr = param_row(r, g, rpg, kq->f.pswap);
+            const float bias = kq->f.bias ? kq->f.bias[pr] : 0.0f;
+
+            // lane vectors (lane 16*row + n = state n of that row)
+            float Av = 0.0f, X0v = 0.0f, Rvv = 0.0f, rvout_v = 0.0f, dA_v = 0.0f;
+            if (li < N) {
+                Av = kq->f.A[(long)pr * kq->f.A_ds + (long)li * kq->f.A_ns];
+                if (j > 0) X0v = kq->f.x[((long)b * kq->f.dim + r) * kq->f.x_rs + (long)(j - 1) * N + li];
+                Rvv = sRv[rl * N + li];
+            }
+            float dl[T], dlu[T], gg[T], sdxB[T], sAx[T];
+            {
+                float dv[T], uu[T];
+                load_items<float, T, REV>(u_row, lbase, L, vec, uu);
+                load_items<float, T, REV>(d_row, lbase, L, vec, dv);
+                load_items<float, T, REV>(g_row, lbase, L, vec, gg);
+#pragma unroll
+                for (int k = 0; k < T; ++k) {
+                    float d = dv[k] + bias;
+                    if (p.softplus) { float sg; d = softplus_ref(d, sg); }
+                    d = (lbase + k < L) ? d : 0.0f;    // identity element past the end (a = 1, b = 0)
+                    dl[k] = d;
+                    dlu[k] = d * uu[k];
+                    sdxB[k] = 0.0f;
+                    sAx[k] = 0.0f;
+                }
+            }
+            float dsum = 0.0f;
+#pragma unroll
+            for (int k = 0; k < T; ++k) dsum += dl[k];
+
+            // row scalars of state 0; those of state n + 1 are fetched while state n is computed
+            float An_nx = row_pick(Av, rowbase4), x0_nx = row_pick(X0v, rowbase4), cy_nx = row_pick(Rvv, rowbase4);
+#pragma unroll 1
+            for (int n = 0; n < N; ++n) {
+                const float An = An_nx, x0 = x0_nx, carry = cy_nx;
+                {
+                    const int nn = (n + 1 < N) ? n + 1 : n;
+                    const int ad = rowbase4 + 4 * nn;
+                    An_nx = row_pick(Av, ad); x0_nx = row_pick(X0v, ad); cy_nx = row_pick(Rvv, ad);
+                }
+                const float A2 = An * kLog2e;
+                const float* tB = cur + n * kTile4;
+                const float* tC = tB + N * kTile4;
+                float a[T], xs[T], gc[T];
+                // ---- forward: in-lane fold (lane 0 of the row starts from the checkpoint), row scan, replay
+                float xa = li0 ? x0 : 0.0f;
+#pragma unroll
+                for (int qq = 0; qq < T / 2; ++qq) {
+                    float bq[2], cq[2];
+                    lds_read_pair<REV>(tB, li, qq, bq);
+                    lds_read_pair<REV>(tC, li, qq, cq);
+#pragma unroll
+                    for (int jj = 0; jj < 2; ++jj) {
+                        const int k = 2 * qq + jj;
+                        a[k] = fast_exp2(dl[k] * A2);
+                        xs[k] = dlu[k] * bq[jj];
+                        gc[k] = gg[k] * cq[jj];
+                        xa = fmaf(a[k], xa, xs[k]);
+                    }
+                }
+                const float plane = fast_exp2(A2 * dsum);       // this lane's decay product
+                float pf = plane;
+                row_mscan_inclusive(pf, xa);
+                const float xstart = dpp_take<DPP_ROW_SHR1, 0xF>(x0, xa);    // state entering the lane
+                {
+                    float x = xstart;
+#pragma unroll
+                    for (int k = 0; k < T; ++k) { x = fmaf(a[k], x, xs[k]); xs[k] = x; }
+                }
+                // ---- reverse: e_k = a_k * dx_k, dx_k = g_k C_k + e_{k+1}; lane 15 of the row starts from the carry
+                float e = li15 ? carry : 0.0f;
+#pragma unroll
+                for (int k = T - 1; k >= 0; --k) e = a[k] * (gc[k] + e);
+                float prv = plane;
+                row_mscan_inclusive_rev(prv, e);
+                e = dpp_take<DPP_ROW_SHL1, 0xF>(carry, e);       // e entering the lane from the right
+                float dAp = 0.0f;
+                const int sidx = ((grp & 1) * SB + (n % SB)) * W + wave;
+                float* __restrict__ slab = sRed + sidx * kCols4 + lane;
+#pragma unroll
+                for (int qq = T / 2 - 1; qq >= 0; --qq) {
+                    float bq[2], vb[2], vc[2];
+                    lds_read_pair<REV>(tB, li, qq, bq);          // B again: cheaper than T live registers
+#pragma unroll
+                    for (int jj = 1; jj >= 0; --jj) {
+                        const int k = 2 * qq + jj;
+                        const float dx = gc[k] + e;
+                        e = a[k] * dx;
+                        sdxB[k] = fmaf(dx, bq[jj], sdxB[k]);
+                        const float t = e * (k > 0 ? xs[k > 0 ? k - 1 : 0] : xstart);   // dx * a_k * x_{k-1}
+                        sAx[k] = fmaf(An, t, sAx[k]);
+                        dAp = fmaf(dl[k], t, dAp);
+                        vb[jj] = dx * dlu[k];                    // this row's term of dB[n, l]
+                        vc[jj] = gg[k] * xs[k];                  // this row's term of dC[n, l]
+                    }
+                    // four-row sums: rows of the result = {dB pos 2qq, dB pos 2qq+1, dC pos 2qq, dC pos 2qq+1}
+                    slab[qq * 64] = fold16(fold32(vb[0], vc[0]), fold32(vb[1], vc[1]));
+                }
+                // collect: lane 0 of each row holds the result of this state; select + rotate, so that after
+                // N states the value of state n sits in lane 16 - N + n
+                rvout_v = row_rotate_left(li0 ? e : rvout_v);
+                const float dA_row = row_sum_to_lane0(dAp);      // all lanes take part: outside the select
+                dA_v = row_rotate_left(li0 ? dA_row : dA_v);
+                if ((n % SB) == SB - 1) {
+                    // slabs of this state group complete; at the end of the tile also "next B/C image landed"
+                    if (n == N - 1 && rb == RB - 1) { lds_dma_wait(); __syncthreads(); } else lds_barrier();
+                    const float* sset = sRed + ((grp & 1) * SB) * W * kCols4;
+                    auto column = [&](int s, int c, int pos, bool is_c) {
+                        const int ns = n - (SB - 1) + s;
+                        const float sum = colsum1(sset + s * W * kCols4 + c, kCols4, W);
+                        if (RB > 1) {
+                            float* ap = sAcc + ns * kCols4 + c;
+                            if (rb == 0) {
+                                *ap = sum;
+                            } else {
+                                const float t = *ap + sum;
+                                if (rb == RB - 1) put_at(ns, l0, pos, is_c, t); else *ap = t;
+                            }
+                        } else {
+                            put_at(ns, l0, pos, is_c, sum);
+                        }
+                    };
+                    if (colS >= 1) {
+                        if (col_s0 < colS)
+                            for (int s = col_s0; s < SB; s += colS) column(s, col_c, my_pos, my_is_c);
+                    } else {
+                        for (int c2 = tid; c2 < SB * kCols4; c2 += blockDim.x) {
+                            const int s = c2 / kCols4;
+                            const int c = c2 - s * kCols4;
+                            bool is_c;
+                            const int pos = col_pos(c, is_c);
+                            column(s, c, pos, is_c);
+                        }
+                    }
+                    ++grp;
+                }
+            }
+
+            // ---- per-row results of this tile (cold parameters re-read here)
+            cold4_t ke = cold_args4();
+            const int rpg2 = ke->f.rows_per_group;
+            const int ur2 = r - ((g - (g >> ke->f.u_gshift)) * rpg2);
+            const float* __restrict__ u_row2 = reinterpret_cast<const float*>(ke->f.u) + (long)b * ke->f.u_bs + (long)ur2 * ke->f.u_ds;
+            const float* __restrict__ d_row2 = reinterpret_cast<const float*>(ke->f.delta) + (long)b * ke->f.dt_bs + (long)r * ke->f.dt_ds;
+            if (li >= vshift) {
+                const int st = li - vshift;
+                sRv[rl * N + st] = rvout_v;
+                atomicAdd(ke->dA + (long)pr * ke->dA_ds + (long)st * ke->dA_ns, dA_v);
+            }
+            float duv[T], ddv[T];
+            float dD_acc = 0.0f, dbias_acc = 0.0f;
+            {
+                const float Dd = ke->f.D ? ke->f.D[pr] : 0.0f;
+                const float bias2 = ke->f.bias ? ke->f.bias[pr] : 0.0f;
+                float dv2[T], uu[T];
+                load_items<float, T, REV>(d_row2, lbase, L, vec, dv2);
+                load_items<float, T, REV>(u_row2, lbase, L, vec, uu);
+#pragma unroll
+                for (int k = 0; k < T; ++k) {
+                    duv[k] = fmaf(Dd, gg[k], dl[k] * sdxB[k]);
+                    float dd = fmaf(uu[k], sdxB[k], sAx[k]);
+                    if (p.softplus) {
+                        const float raw = dv2[k] + bias2;
+                        const float ez = fast_exp2(raw * kLog2e);
+                        dd *= (raw > 20.0f) ? 1.0f : ez * fast_rcp(1.0f + ez);
+                    }
+                    ddv[k] = dd;
+                    if (lbase + k < L) { dD_acc = fmaf(gg[k], uu[k], dD_acc); dbias_acc += dd; }
+                }
+            }
+            float* __restrict__ du_row = reinterpret_cast<float*>(ke->du) + (long)b * ke->du_bs + (long)r * ke->du_ds;
+            float* __restrict__ dd_row = reinterpret_cast<float*>(ke->ddelta) + (long)b * ke->dd_bs + (long)r * ke->dd_ds;
+            store_items<float, T, REV>(du_row, lbase, L, vec, duv);
+            store_items<float, T, REV>(dd_row, lbase, L, vec, ddv);
+            if (ke->dD) { dD_acc = row_sum_to_lane0(dD_acc); if (li0) atomicAdd(ke->dD + pr, dD_acc); }
+            if (ke->dbias) { dbias_acc = row_sum_to_lane0(dbias_acc); if (li0) atomicAdd(ke->dbias + pr, dbias_acc); }
+        }
+        buf ^= 1;
+    }
+}
+
+template <int MAXW>
+__global__ void __launch_bounds__(64 * MAXW)
+scan_bwd4_kernel(const BwdArgs q) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lb = xcd_logical_block(blockIdx.x, gridDim.x);
+    const int per_b = q.f.G * q.P;                    // workgroups per batch entry
+    const int b = lb / per_b;
+    const int rem = lb - b * per_b;
+    const int g = rem / q.P;
+    const int chunk = rem - g * q.P;
+    if ((q.f.rev_mask >> g) & 1u) scan_bwd4_body<true>(q, smem, b, g, chunk);
+    else scan_bwd4_body<false>(q, smem, b, g, chunk);
+}
+
+// a.f.R = waves per workgroup (4 rows each), a.slab2 = states per barrier, a.RB = row blocks per workgroup
+hipError_t launch_scan_bwd4(const BwdArgs& a, hipStream_t stream) {
+    const size_t lds = bwd4_lds_bytes(a.f.R, a.f.N, a.slab2, a.RB);
+    const int grid = a.f.batch * a.f.G * a.P;
+    auto kern = scan_bwd4_kernel<12>;
+    static std::atomic<size_t> lds_cap[kMaxDevices];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= kMaxDevices) dev = 0;
+    if (lds > 48 * 1024 && lds > lds_cap[dev].load(std::memory_order_relaxed)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        lds_cap[dev].store(lds, std::memory_order_relaxed);
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(a.f.R * 64), lds, stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess || a.P == 1) return e;
+    return launch_reduce_partials(a, stream);
+}
+
+}  // namespace sigma

@@ -151,7 +151,8 @@ def fwd_ext(u, delta, A, B, C, D_, delta_bias_, delta_softplus, nrows: int = 1, 
     out = torch.empty_like(delta)                                   # selective_scan.cpp:226
     if fine_ckpt and not ckpt_pitch:
         ckpt_pitch = _capi.SIGMA_SCAN_CKPT_PITCH_FINE
-    _check(ckpt_pitch in (0, _capi.SIGMA_SCAN_CKPT_PITCH_FINE, _capi.SIGMA_SCAN_CKPT_PITCH_320), "ckpt_pitch must be 0, 640 or 320")
+    _check(ckpt_pitch in (0, _capi.SIGMA_SCAN_CKPT_PITCH_FINE, _capi.SIGMA_SCAN_CKPT_PITCH_320, _capi.SIGMA_SCAN_CKPT_PITCH_160),
+           "ckpt_pitch must be 0, 640, 320 or 160")
     if ckpt_pitch:
         ncp = (seqlen + ckpt_pitch - 1) // ckpt_pitch
         x = torch.empty((batch, dim, max(ncp, 1) * dstate), device=u.device, dtype=torch.float32)

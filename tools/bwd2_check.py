@@ -19,7 +19,7 @@ from sigma_amd import _capi                                    # noqa: E402
 from sigma_amd import selective_scan_cuda_core as core         # noqa: E402
 from tools.scan_bench import SHAPES, make, time_call, bwd_bytes   # noqa: E402
 
-OPTS = ("bwd_gen", "bwd_items", "bwd_waves", "bwd_nb", "bwd_slab2", "bwd_rb")
+OPTS = ("bwd_gen", "bwd_items", "bwd_waves", "bwd_nb", "bwd_slab2", "bwd_rb", "bwd_sb")
 
 
 def bwd_plan(shape, pitch):
@@ -120,7 +120,11 @@ def check():
                     (320, dict(bwd_gen=2)), (320, dict(bwd_gen=2, bwd_rb=8)),
                     (320, dict(bwd_gen=3)), (320, dict(bwd_gen=3, bwd_waves=12)), (320, dict(bwd_gen=3, bwd_rb=1)),
                     (320, dict(bwd_gen=3, bwd_waves=8, bwd_rb=2))]
+        if os.environ.get("CHECK_VARIANTS"):      # JSON [[pitch, {option: value}], ...]
+            variants = [(int(v[0]), dict(v[1])) for v in json.loads(os.environ["CHECK_VARIANTS"])]
         for pitch, opts in variants:
+            if pitch == 160 and (dt != torch.float32 or L % 4 != 0):
+                continue                          # quad-row backward: f32 IO, LDS-DMA staging (L % 4 == 0)
             out, x = core.fwd_ext(*args, True, rev_mask=mask, u_gshift=ush, ckpt_pitch=pitch)
             mark(f"fwd pitch {pitch} done")
             plan = None
@@ -162,7 +166,7 @@ def bench(names):
         u, delta, A, Bm, Cm, D, bias, dout = make(shape)
         bb = bwd_bytes(*shape)
         xs = {}
-        for pitch in (640, 320):
+        for pitch in (640, 320, 160):
             xs[pitch] = core.fwd_ext(u, delta, A, Bm, Cm, D, bias, True, ckpt_pitch=pitch)[1]
         variants = [
             ("v1 fine", 640, dict(bwd_gen=1)),
@@ -173,6 +177,8 @@ def bench(names):
             ("T5 rb1", 320, dict(bwd_rb=1, bwd_gen=2)),
             ("T5 v2 auto", 320, dict(bwd_gen=2)),
         ]
+        if os.environ.get("VARIANTS"):       # JSON [[label, pitch, {option: value}], ...]
+            variants = [tuple(v) for v in json.loads(os.environ["VARIANTS"])]
         for label, pitch, opts in variants:
             x = xs[pitch]
             try:
