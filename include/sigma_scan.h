@@ -181,8 +181,10 @@ int sigma_scan_abi_version(void);
  *   "bwd_gen"                  1 = first-generation backward (scan_bwd.hip) always, 2 = second generation
  *                              (scan_bwd2.hip: needs ckpt_pitch 640 / 320 and dstate <= 64) whenever legal
  *   "bwd_rb"                   second-generation backward: row blocks a workgroup accumulates over (0..256)
- *   "bwd_touch"                1 = second-generation backward warms L2 with the next row step's u/delta/dout lines
- *                              (about 1% faster, but every line is fetched twice: profiles/r02_pmc_touch.txt)
+ *   "bwd_touch"                L2 warm-up of the next row step's u/delta/dout lines: 1 = on, 2 = off, 0 = on in the
+ *                              quad-row backward (touches 3 states ahead: -3..-6 %), off in the second generation (there
+ *                              a whole row step ahead: every line fetched twice for 1 %, profiles/r02_pmc_enc_s2_b16.txt)
+ *   "bwd_sb"                   quad-row backward (ckpt_pitch 160): states per barrier {1, 2, 4, 8}; 0 = 2
  * Returns SIGMA_ERR_BAD_OPTION for unknown names / unsupported values. */
 int sigma_scan_set_option(const char *name, int value);
 int sigma_scan_get_option(const char *name);

@@ -376,24 +376,35 @@ Plan4 plan_bwd4(const sigma_scan_fwd_params* p, bool vec) {
     if (rpg % 4 != 0) return pl;
     const int quads = rpg / 4;                                       // wave-sized row quads per group
     const int fr = g_opt_bwd_waves.load();
-    // workgroups wanted: one per CU at least; fewer waves per workgroup when the problem has few rows
-    int W = 0;
-    if (fr > 0 && fr <= 12 && quads % fr == 0) W = fr;
-    for (int w = 12; W == 0 && w >= 1; --w) {
+    // Geometry = (waves W per workgroup, row blocks RB it walks per tile).  Estimated time ~ rounds of workgroups
+    // over the 256 CUs x rows a workgroup walks per tile x cost per row, where the per-row cost falls with the
+    // workgroup size (B/C staging, barriers and column sums are per-workgroup costs; 16 waves = four per SIMD in
+    // the 128-VGPR build): measured on (16,3072,1200,N16) 918 / 979 / 1185 us for W = 16 / 12 / 8 at equal grids
+    // (profiles/r02_bwd4_shapes.txt).  Ties go to more row blocks (fewer partial dB/dC slabs).
+    const int frb = g_opt_bwd_rb.load();
+    const long bg = (long)p->batch * p->n_groups;
+    int W = 0, RB = 1;
+    double best = 1e300;
+    for (int w = 16; w >= 1; --w) {
         if (quads % w != 0) continue;
-        if ((long)p->batch * p->n_groups * (quads / w) >= kCUs || w <= 4) W = w;
+        if (fr > 0 && fr <= 16 && quads % fr == 0 && w != fr) continue;          // forced waves (when legal)
+        const int rowblocks_w = quads / w;
+        for (int d = rowblocks_w; d >= 1; --d) {
+            if (rowblocks_w % d != 0) continue;
+            if (frb > 0) {                                                       // forced row blocks: largest divisor <= frb
+                int want = frb;
+                while (want > 1 && rowblocks_w % want != 0) --want;
+                if (d != want) continue;
+            }
+            if ((size_t)d * 4 * w * N * sizeof(float) > 48 * 1024) continue;     // reverse carries of the chunk's rows
+            const long grid = bg * (rowblocks_w / d);
+            const double rounds = (double)((grid + kCUs - 1) / kCUs);
+            const double cost = rounds * d * w * (0.73 + 4.3 / w);
+            if (cost < best * 0.999) { best = cost; W = w; RB = d; }
+        }
     }
     if (W == 0) return pl;
     const int rowblocks = quads / W;
-    int RB = 1;
-    const int frb = g_opt_bwd_rb.load();
-    if (frb > 0) {
-        RB = frb;
-        while (RB > 1 && rowblocks % RB != 0) --RB;
-    } else {
-        for (int d = 1; d <= rowblocks; ++d)
-            if (rowblocks % d == 0 && (long)p->batch * p->n_groups * (rowblocks / d) >= kCUs) RB = d;
-    }
     int SB = g_opt_bwd_sb.load() > 0 ? g_opt_bwd_sb.load() : 2;
     while (SB > 1 && N % SB != 0) SB >>= 1;
     while (sigma::bwd4_lds_bytes(W, N, SB, RB) > kLdsLimit) {
@@ -431,7 +442,7 @@ OptDesc g_opts[] = {
     {"fwd_prefetch", &g_opt_fwd_prefetch, {0, 1, 2, -1}},  // 2 = no register prefetch of the next tile's u/delta (T = 10)
     {"bwd_gen", &g_opt_bwd_gen, {0, 1, 2, 3, -1}},         // backward kernel: 1 = scan_bwd.hip, 2 = scan_bwd2.hip, 3 / 0 = best legal
     {"bwd_sb", &g_opt_bwd_sb, {0, 1, 2, 4, 8, -1}},          // quad-row backward: states per barrier (0 = 2)
-    {"bwd_touch", &g_opt_bwd_touch, {0, 1, -1}},   // 1 = L2 warm-up touches of the next row step (doubles FETCH_SIZE, ~1% faster)
+    {"bwd_touch", &g_opt_bwd_touch, {0, 1, 2, -1}},   // L2 warm-up touches of the next row step: 1 = on, 2 = off, 0 = on in scan_bwd4 only
     {"bwd_rb", &g_opt_bwd_rb, {-3}},                       // scan_bwd2: row blocks per workgroup, 0..256
 };
 }  // namespace
@@ -602,7 +613,10 @@ int sigma_selective_scan_bwd(const sigma_scan_bwd_params* q, void* stream) {
                     q->dC_group_stride % 4 == 0 && q->dC_dstate_stride % 4 == 0) ? 1 : 0;
     a.ws_dB = P > 1 ? static_cast<float*>(q->workspace) : nullptr;
     a.ws_dC = P > 1 ? static_cast<float*>(q->workspace) + slab : nullptr;
-    a.flags = g_opt_bwd_touch.load() ? 0 : 1;
+    {
+        const int t = g_opt_bwd_touch.load();        // bit 0 of flags = NO touches
+        a.flags = (t == 1 || (t == 0 && p4.ok)) ? 0 : 1;
+    }
     a.RB = p4.ok ? p4.RB : p3.ok ? p3.RB : (p2.ok ? p2.RB : 1);
     if (p4.ok) a.slab2 = p4.SB;
     hipError_t e = p4.ok ? sigma::launch_scan_bwd4(a, static_cast<hipStream_t>(stream)) : p3.ok ? sigma::launch_scan_bwd3(a, p->io_dtype, pl.glds, static_cast<hipStream_t>(stream)) : p2.ok ? sigma::launch_scan_bwd2(a, p->io_dtype, pl.items, pl.glds, static_cast<hipStream_t>(stream))
@@ -615,6 +629,7 @@ int sigma_scan_debug_read(uint64_t out16[16]) {
     if (!out16) return fail(SIGMA_ERR_NULL_ARG, "out16 is NULL");
     hipError_t e = hipDeviceSynchronize();
     if (e == hipSuccess) e = sigma::bwd2_prof_read(reinterpret_cast<unsigned long long*>(out16));
+    if (e == hipSuccess && out16[15] == 0) e = sigma::bwd4_prof_read(reinterpret_cast<unsigned long long*>(out16));   // quad-row kernel ran
     if (e != hipSuccess) return fail(SIGMA_ERR_LAUNCH, "debug read failed: %s", hipGetErrorString(e));
     return SIGMA_OK;
 }

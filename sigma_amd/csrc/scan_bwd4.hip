@@ -27,7 +27,34 @@
 
 #include <atomic>
 
+// phase timing of development builds, as in scan_bwd2.hip (-DSIGMA_BWD2_PROF=1; tools/bwd2_prof.py)
+#ifndef SIGMA_BWD2_PROF
+#define SIGMA_BWD2_PROF 0
+#endif
+#if SIGMA_BWD2_PROF
+__device__ unsigned long long g_bwd4_prof[16];
+#define PROF_DECL long long prof_t[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long prof_last = __builtin_readcyclecounter();
+#define PROF(i) { const long long t_ = __builtin_readcyclecounter(); prof_t[i] += t_ - prof_last; prof_last = t_; }
+#define PROF_FLUSH if ((threadIdx.x & 63) == 0) { for (int i_ = 0; i_ < 10; ++i_) atomicAdd(&g_bwd4_prof[i_], (unsigned long long)prof_t[i_]); atomicAdd(&g_bwd4_prof[15], 1ull); }
+#else
+#define PROF_DECL
+#define PROF(i)
+#define PROF_FLUSH
+#endif
+
 namespace sigma {
+
+#if SIGMA_BWD2_PROF
+hipError_t bwd4_prof_read(unsigned long long* out16) {
+    hipError_t e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_bwd4_prof), 16 * sizeof(unsigned long long));
+    if (e != hipSuccess) return e;
+    unsigned long long z[16] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_bwd4_prof), z, sizeof(z));
+}
+#else
+hipError_t bwd4_prof_read(unsigned long long* out16) { for (int i = 0; i < 16; ++i) out16[i] = 0; return hipSuccess; }
+#endif
+
 namespace {
 
 constexpr int kT4 = 10;            // positions per lane
@@ -80,6 +107,19 @@ __device__ __forceinline__ void stage_tile4(float* dst, const float* Bg, const f
     }
 }
 
+// L2 warm-up of the u / delta / dout segments (640 B per row) the wave loads in its NEXT row step: lane
+// 6*row + line touches one 128-byte line through LDS-DMA into a dummy area (no VGPR destination; untracked like
+// the B/C stream, retired by the next vmcnt wait).  Issued a few states before the end of the current row step,
+// so the lines are still in L2 when the real loads arrive: the ~2 us HBM miss that all waves of the workgroup
+// would otherwise sit out together at the top of a row step becomes an L2 hit.
+__device__ __forceinline__ void touch_line4(const char* pa, bool on, unsigned lds_dummy) {
+    if (on) {
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(pa), "s"(lds_dummy) : "memory");
+    }
+}
+
 // positions 2q, 2q+1 of the lane's 10 (li = lane inside its DPP row); the image is in memory order
 template <bool REV>
 __device__ __forceinline__ void lds_read_pair(const float* __restrict__ tile, int li, int q, float (&v)[2]) {
@@ -87,6 +127,19 @@ __device__ __forceinline__ void lds_read_pair(const float* __restrict__ tile, in
     const float2 x = *reinterpret_cast<const float2*>(src);
     v[0] = REV ? x.y : x.x;
     v[1] = REV ? x.x : x.y;
+}
+
+// store positions 2q, 2q+1 of the lane's 10 (same addressing as store_items<float, 10, REV>)
+template <bool REV>
+__device__ __forceinline__ void store_pair(float* __restrict__ row, int lbase, int L, bool vec, int q, float v0, float v1) {
+    if (vec && lbase + kT4 <= L) {
+        float* __restrict__ dst = row + (REV ? (L - lbase - kT4) + (kT4 - 2 - 2 * q) : lbase + 2 * q);
+        *reinterpret_cast<float2*>(dst) = REV ? make_float2(v1, v0) : make_float2(v0, v1);
+    } else {
+        const int p0 = lbase + 2 * q;
+        if (p0 < L) row[REV ? (L - 1 - p0) : p0] = v0;
+        if (p0 + 1 < L) row[REV ? (L - 2 - p0) : p0 + 1] = v1;
+    }
 }
 
 // ---- scans inside one DPP row (16 lanes): the first four steps of wave_mscan_inclusive{,_rev}
@@ -182,7 +235,8 @@ __device__ __forceinline__ void scan_bwd4_body(const BwdArgs& q, float* smem, in
     float* sBC = smem;                                // [2][2][N][160]
     float* sRed = sBC + 2 * bufsz;                    // [2*SB][W][320] four-row sums of the dB/dC terms
     float* sRv = sRed + 2 * SB * W * kCols4;          // [RB*4*W][N] reverse carry a*dx of the tile to the right
-    float* sAcc = sRv + RB * 4 * W * N;               // [N][320] when RB > 1
+    float* sSink = sRv + RB * 4 * W * N;              // 64 floats: target of the L2 warm-up touches
+    float* sAcc = sSink + 64;                         // [N][320] when RB > 1
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -244,9 +298,11 @@ __device__ __forceinline__ void scan_bwd4_body(const BwdArgs& q, float* smem, in
 
     int buf = 0;
     int grp = 0;                                       // state groups processed (slab set parity)
+    PROF_DECL
     stage(0, ntiles - 1);
     lds_dma_wait();
     __syncthreads();
+    PROF(0)
 
     for (int j = ntiles - 1; j >= 0; --j) {
         const int l0 = j * kTile4;
@@ -274,6 +330,7 @@ __device__ __forceinline__ void scan_bwd4_body(const BwdArgs& q, float* smem, in
                 Rvv = sRv[rl * N + li];
             }
             float dl[T], dlu[T], gg[T], sdxB[T], sAx[T];
+            float dD_acc = 0.0f;                       // sum of dout * u over the lane's positions (zero past the end)
             {
                 float dv[T], uu[T];
                 load_items<float, T, REV>(u_row, lbase, L, vec, uu);
@@ -286,6 +343,7 @@ __device__ __forceinline__ void scan_bwd4_body(const BwdArgs& q, float* smem, in
                     d = (lbase + k < L) ? d : 0.0f;    // identity element past the end (a = 1, b = 0)
                     dl[k] = d;
                     dlu[k] = d * uu[k];
+                    dD_acc = fmaf(gg[k], uu[k], dD_acc);
                     sdxB[k] = 0.0f;
                     sAx[k] = 0.0f;
                 }
@@ -293,7 +351,9 @@ __device__ __forceinline__ void scan_bwd4_body(const BwdArgs& q, float* smem, in
             float dsum = 0.0f;
 #pragma unroll
             for (int k = 0; k < T; ++k) dsum += dl[k];
+            if (kq->dD) { dD_acc = row_sum_to_lane0(dD_acc); if (li0) atomicAdd(kq->dD + pr, dD_acc); }
 
+            PROF(1)                                            // row prologue: loads, softplus
             // row scalars of state 0; those of state n + 1 are fetched while state n is computed
             float An_nx = row_pick(Av, rowbase4), x0_nx = row_pick(X0v, rowbase4), cy_nx = row_pick(Rvv, rowbase4);
 #pragma unroll 1
@@ -303,6 +363,27 @@ __device__ __forceinline__ void scan_bwd4_body(const BwdArgs& q, float* smem, in
                     const int nn = (n + 1 < N) ? n + 1 : n;
                     const int ad = rowbase4 + 4 * nn;
                     An_nx = row_pick(Av, ad); x0_nx = row_pick(X0v, ad); cy_nx = row_pick(Rvv, ad);
+                }
+                if (n == N - 3 && !(q.flags & 1)) {
+                    // next step of THIS wave: same tile, next row block -- or the tile to the left of its first rows
+                    const int jn = (rb + 1 < RB) ? j : j - 1;
+                    if (jn >= 0) {
+                        cold4_t kt = cold_args4();
+                        const int trow = lane / 6, tline = lane - trow * 6;          // 24 lanes: 4 rows x 6 lines
+                        const int rn = row_c0 + (((rb + 1 < RB) ? rb + 1 : 0) * W + wave) * 4 + trow;
+                        const int rpgt = kt->f.rows_per_group;
+                        const int urn = rn - ((g - (g >> kt->f.u_gshift)) * rpgt);
+                        const int grn = rn - ((g - (g >> kt->g_gshift)) * rpgt);
+                        const int l0n = jn * kTile4;
+                        const int m0 = REV ? (L - l0n - kTile4 < 0 ? 0 : L - l0n - kTile4) : l0n;      // first memory element
+                        const int m1 = REV ? L - l0n : (l0n + kTile4 < L ? l0n + kTile4 : L);
+                        const bool on = trow < 4 && tline * 32 < (m1 - m0) + 31;
+                        const int me = m0 + tline * 32 < m1 ? m0 + tline * 32 : m1 - 1;                // element inside the line
+                        const unsigned sink = (unsigned)(uintptr_t)(lptr_t)sSink;
+                        touch_line4(reinterpret_cast<const char*>(reinterpret_cast<const float*>(kt->f.u) + (long)b * kt->f.u_bs + (long)urn * kt->f.u_ds + me), on, sink);
+                        touch_line4(reinterpret_cast<const char*>(reinterpret_cast<const float*>(kt->f.delta) + (long)b * kt->f.dt_bs + (long)rn * kt->f.dt_ds + me), on, sink);
+                        touch_line4(reinterpret_cast<const char*>(reinterpret_cast<const float*>(kt->dout) + (long)b * kt->g_bs + (long)grn * kt->g_ds + me), on, sink);
+                    }
                 }
                 const float A2 = An * kLog2e;
                 const float* tB = cur + n * kTile4;
@@ -326,6 +407,7 @@ __device__ __forceinline__ void scan_bwd4_body(const BwdArgs& q, float* smem, in
                 }
                 const float plane = fast_exp2(A2 * dsum);       // this lane's decay product
                 float pf = plane;
+                PROF(2)                                        // B/C reads, exp, forward fold
                 row_mscan_inclusive(pf, xa);
                 const float xstart = dpp_take<DPP_ROW_SHR1, 0xF>(x0, xa);    // state entering the lane
                 {
@@ -333,6 +415,7 @@ __device__ __forceinline__ void scan_bwd4_body(const BwdArgs& q, float* smem, in
 #pragma unroll
                     for (int k = 0; k < T; ++k) { x = fmaf(a[k], x, xs[k]); xs[k] = x; }
                 }
+                PROF(3)                                        // forward scan + replay
                 // ---- reverse: e_k = a_k * dx_k, dx_k = g_k C_k + e_{k+1}; lane 15 of the row starts from the carry
                 float e = li15 ? carry : 0.0f;
 #pragma unroll
@@ -341,6 +424,7 @@ __device__ __forceinline__ void scan_bwd4_body(const BwdArgs& q, float* smem, in
                 row_mscan_inclusive_rev(prv, e);
                 e = dpp_take<DPP_ROW_SHL1, 0xF>(carry, e);       // e entering the lane from the right
                 float dAp = 0.0f;
+                PROF(4)                                        // reverse fold + scan
                 const int sidx = ((grp & 1) * SB + (n % SB)) * W + wave;
                 float* __restrict__ slab = sRed + sidx * kCols4 + lane;
 #pragma unroll
@@ -367,9 +451,11 @@ __device__ __forceinline__ void scan_bwd4_body(const BwdArgs& q, float* smem, in
                 rvout_v = row_rotate_left(li0 ? e : rvout_v);
                 const float dA_row = row_sum_to_lane0(dAp);      // all lanes take part: outside the select
                 dA_v = row_rotate_left(li0 ? dA_row : dA_v);
+                PROF(5)                                        // reverse replay, four-row sums, slab writes, collect
                 if ((n % SB) == SB - 1) {
                     // slabs of this state group complete; at the end of the tile also "next B/C image landed"
                     if (n == N - 1 && rb == RB - 1) { lds_dma_wait(); __syncthreads(); } else lds_barrier();
+                    PROF(6)                                    // barrier wait
                     const float* sset = sRed + ((grp & 1) * SB) * W * kCols4;
                     auto column = [&](int s, int c, int pos, bool is_c) {
                         const int ns = n - (SB - 1) + s;
@@ -399,50 +485,82 @@ __device__ __forceinline__ void scan_bwd4_body(const BwdArgs& q, float* smem, in
                         }
                     }
                     ++grp;
+                    PROF(7)                                    // column sums
                 }
             }
 
             // ---- per-row results of this tile (cold parameters re-read here)
+            // Row indices are rebuilt from the (laundered) lane id: otherwise r, pr, lbase and the address parts the
+            // compiler pre-computes from them stay live across the state loop -- in the 128-VGPR build as scratch spills.
             cold4_t ke = cold_args4();
-            const int rpg2 = ke->f.rows_per_group;
-            const int ur2 = r - ((g - (g >> ke->f.u_gshift)) * rpg2);
-            const float* __restrict__ u_row2 = reinterpret_cast<const float*>(ke->f.u) + (long)b * ke->f.u_bs + (long)ur2 * ke->f.u_ds;
-            const float* __restrict__ d_row2 = reinterpret_cast<const float*>(ke->f.delta) + (long)b * ke->f.dt_bs + (long)r * ke->f.dt_ds;
-            if (li >= vshift) {
-                const int st = li - vshift;
-                sRv[rl * N + st] = rvout_v;
-                atomicAdd(ke->dA + (long)pr * ke->dA_ds + (long)st * ke->dA_ns, dA_v);
+            int lane_e = lane;
+            asm volatile("" : "+v"(lane_e));
+            const int li_e = lane_e & 15;
+            const int rl_e = (rb * W + wave) * 4 + (lane_e >> 4);
+            const int r_e = row_c0 + rl_e;
+            const int pr_e = param_row(r_e, g, ke->f.rows_per_group, ke->f.pswap);
+            const int lbase_e = l0 + li_e * T;
+            if (li_e >= vshift) {
+                const int st = li_e - vshift;
+                sRv[rl_e * N + st] = rvout_v;
+                atomicAdd(ke->dA + (long)pr_e * ke->dA_ds + (long)st * ke->dA_ns, dA_v);
             }
-            float duv[T], ddv[T];
-            float dD_acc = 0.0f, dbias_acc = 0.0f;
+            float dbias_acc = 0.0f;
+            float* __restrict__ du_row = reinterpret_cast<float*>(ke->du) + (long)b * ke->du_bs + (long)r_e * ke->du_ds;
+            float* __restrict__ dd_row = reinterpret_cast<float*>(ke->ddelta) + (long)b * ke->dd_bs + (long)r_e * ke->dd_ds;
             {
-                const float Dd = ke->f.D ? ke->f.D[pr] : 0.0f;
-                const float bias2 = ke->f.bias ? ke->f.bias[pr] : 0.0f;
-                float dv2[T], uu[T];
-                load_items<float, T, REV>(d_row2, lbase, L, vec, dv2);
-                load_items<float, T, REV>(u_row2, lbase, L, vec, uu);
+                const float Dd = ke->f.D ? ke->f.D[pr_e] : 0.0f;
+                if (p.softplus) {
+                    // Nothing is re-read here (the row epilogue was 19 % of the kernel waiting for u and delta again,
+                    // profiles/r02_bwd4_phases.txt): with dl = softplus(raw) > 0,
+                    //   u * sdxB            = (dl*u) * sdxB / dl
+                    //   softplus'(raw)      = sigmoid(raw) = 1 - exp(-dl) = -expm1(-dl)
+                    // -expm1(-dl): 1 - exp2 above 0.25 (relative error < 3e-7), a degree-7 series below (< 1e-7).
+                    // dl == 0 only past the end of the row or where exp(raw) underflows, i.e. sigmoid(raw) = 0 too.
+                    auto dd_of = [&](int k) {
+                        const float d = dl[k];
+                        const bool live = d >= 1.17549435e-38f;
+                        const float usx = dlu[k] * (sdxB[k] * fast_rcp(live ? d : 1.0f));
+                        const float big = 1.0f - fast_exp2(-d * kLog2e);
+                        float ser = fmaf(d, -1.0f / 7.0f, 1.0f);
+                        ser = fmaf(ser * d, -1.0f / 6.0f, 1.0f);
+                        ser = fmaf(ser * d, -1.0f / 5.0f, 1.0f);
+                        ser = fmaf(ser * d, -1.0f / 4.0f, 1.0f);
+                        ser = fmaf(ser * d, -1.0f / 3.0f, 1.0f);
+                        ser = fmaf(ser * d, -1.0f / 2.0f, 1.0f);
+                        const float sig = d > 0.25f ? big : ser * d;
+                        return live ? (usx + sAx[k]) * sig : 0.0f;
+                    };
 #pragma unroll
-                for (int k = 0; k < T; ++k) {
-                    duv[k] = fmaf(Dd, gg[k], dl[k] * sdxB[k]);
-                    float dd = fmaf(uu[k], sdxB[k], sAx[k]);
-                    if (p.softplus) {
-                        const float raw = dv2[k] + bias2;
-                        const float ez = fast_exp2(raw * kLog2e);
-                        dd *= (raw > 20.0f) ? 1.0f : ez * fast_rcp(1.0f + ez);
+                    for (int qq = 0; qq < T / 2; ++qq) {
+                        const int k = 2 * qq;
+                        store_pair<REV>(du_row, lbase_e, L, vec, qq, fmaf(Dd, gg[k], dl[k] * sdxB[k]), fmaf(Dd, gg[k + 1], dl[k + 1] * sdxB[k + 1]));
+                        const float d0 = dd_of(k), d1 = dd_of(k + 1);
+                        store_pair<REV>(dd_row, lbase_e, L, vec, qq, d0, d1);
+                        dbias_acc += d0 + d1;          // zero past the end (dl = 0 there)
                     }
-                    ddv[k] = dd;
-                    if (lbase + k < L) { dD_acc = fmaf(gg[k], uu[k], dD_acc); dbias_acc += dd; }
+                } else {
+                    const int rpg2 = ke->f.rows_per_group;
+                    const int ur2 = r_e - ((g - (g >> ke->f.u_gshift)) * rpg2);
+                    const float* __restrict__ u_row2 = reinterpret_cast<const float*>(ke->f.u) + (long)b * ke->f.u_bs + (long)ur2 * ke->f.u_ds;
+                    float uu[T];
+                    load_items<float, T, REV>(u_row2, lbase_e, L, vec, uu);
+#pragma unroll
+                    for (int qq = 0; qq < T / 2; ++qq) {
+                        const int k = 2 * qq;
+                        store_pair<REV>(du_row, lbase_e, L, vec, qq, fmaf(Dd, gg[k], dl[k] * sdxB[k]), fmaf(Dd, gg[k + 1], dl[k + 1] * sdxB[k + 1]));
+                        const float d0 = fmaf(uu[k], sdxB[k], sAx[k]), d1 = fmaf(uu[k + 1], sdxB[k + 1], sAx[k + 1]);
+                        store_pair<REV>(dd_row, lbase_e, L, vec, qq, d0, d1);
+                        dbias_acc += ((lbase_e + k < L) ? d0 : 0.0f) + ((lbase_e + k + 1 < L) ? d1 : 0.0f);
+                    }
                 }
             }
-            float* __restrict__ du_row = reinterpret_cast<float*>(ke->du) + (long)b * ke->du_bs + (long)r * ke->du_ds;
-            float* __restrict__ dd_row = reinterpret_cast<float*>(ke->ddelta) + (long)b * ke->dd_bs + (long)r * ke->dd_ds;
-            store_items<float, T, REV>(du_row, lbase, L, vec, duv);
-            store_items<float, T, REV>(dd_row, lbase, L, vec, ddv);
-            if (ke->dD) { dD_acc = row_sum_to_lane0(dD_acc); if (li0) atomicAdd(ke->dD + pr, dD_acc); }
-            if (ke->dbias) { dbias_acc = row_sum_to_lane0(dbias_acc); if (li0) atomicAdd(ke->dbias + pr, dbias_acc); }
+            if (ke->dbias) { dbias_acc = row_sum_to_lane0(dbias_acc); if (li_e == 0) atomicAdd(ke->dbias + pr_e, dbias_acc); }
+            PROF(8)                                            // row epilogue
         }
         buf ^= 1;
     }
+    PROF_FLUSH
 }
 
 template <int MAXW>
@@ -460,10 +578,11 @@ scan_bwd4_kernel(const BwdArgs q) {
 }
 
 // a.f.R = waves per workgroup (4 rows each), a.slab2 = states per barrier, a.RB = row blocks per workgroup
-hipError_t launch_scan_bwd4(const BwdArgs& a, hipStream_t stream) {
+template <int MAXW>
+static hipError_t launch_bwd4_t(const BwdArgs& a, hipStream_t stream) {
     const size_t lds = bwd4_lds_bytes(a.f.R, a.f.N, a.slab2, a.RB);
     const int grid = a.f.batch * a.f.G * a.P;
-    auto kern = scan_bwd4_kernel<12>;
+    auto kern = scan_bwd4_kernel<MAXW>;
     static std::atomic<size_t> lds_cap[kMaxDevices];
     int dev = 0;
     (void)hipGetDevice(&dev);
@@ -478,6 +597,11 @@ hipError_t launch_scan_bwd4(const BwdArgs& a, hipStream_t stream) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || a.P == 1) return e;
     return launch_reduce_partials(a, stream);
+}
+
+hipError_t launch_scan_bwd4(const BwdArgs& a, hipStream_t stream) {
+    // up to 12 waves: ~150 VGPRs, 3 waves per SIMD; 13..16 waves: the 128-VGPR build
+    return a.f.R > 12 ? launch_bwd4_t<16>(a, stream) : launch_bwd4_t<12>(a, stream);
 }
 
 }  // namespace sigma

@@ -45,7 +45,7 @@ inline size_t bwd3_lds_bytes(int nw, int N, int RB) {
 // scan_bwd4 (quad-row): B/C image of one 160-tile for all states, double-buffered [2][2][N][160] + 2*SB slab
 // sets [W][320] + reverse carries of the chunk's RB*4*W rows + the dB/dC accumulators [N][320] when RB > 1
 inline size_t bwd4_lds_bytes(int W, int N, int SB, int RB) {
-    return sizeof(float) * (2 * 2 * (size_t)N * 160 + 2 * (size_t)SB * W * 320 + (size_t)RB * 4 * W * N + (RB > 1 ? (size_t)N * 320 : 0));
+    return sizeof(float) * (2 * 2 * (size_t)N * 160 + 2 * (size_t)SB * W * 320 + (size_t)RB * 4 * W * N + 64 + (RB > 1 ? (size_t)N * 320 : 0));
 }
 
 constexpr int kMaxDevices = 16;    // per-device cache of the raised dynamic-LDS cap (hipFuncSetAttribute is per device)
@@ -54,6 +54,7 @@ hipError_t launch_scan_bwd2(const BwdArgs& a, int dtype, int T, bool glds, hipSt
 hipError_t launch_scan_bwd3(const BwdArgs& a, int dtype, bool glds, hipStream_t stream);   // a.f.R = waves per workgroup
 hipError_t launch_scan_bwd4(const BwdArgs& a, hipStream_t stream);   // a.f.R = waves (4 rows each), a.slab2 = states per barrier
 hipError_t launch_reduce_partials(const BwdArgs& a, hipStream_t stream);
+hipError_t bwd4_prof_read(unsigned long long* out16);
 hipError_t bwd2_prof_read(unsigned long long* out16);     // development builds (SIGMA_BWD2_PROF), zeros otherwise
 hipError_t launch_scan_fwd(const FwdArgs& a, int dtype, int T, bool glds, bool prefetch, hipStream_t stream);
 hipError_t launch_scan_bwd(const BwdArgs& a, int dtype, int T, bool glds, hipStream_t stream);

@@ -48,7 +48,8 @@ class SelectiveScanFn(torch.autograd.Function):
         # x never leaves this Function, so it is allocated with one checkpoint per backward tile
         # (include/sigma_scan.h, ckpt_pitch): the backward then runs csrc/scan_bwd2.hip.  The module-level
         # ``selective_scan_cuda_core.fwd`` keeps the reference-shaped x (selective_scan.cpp:225-228).
-        ctx.pitch = ckpt_pitch_for(u.shape[-1], A.shape[1], delta.shape[0] * delta.shape[1])
+        ctx.pitch = ckpt_pitch_for(u.shape[-1], A.shape[1], delta.shape[0] * delta.shape[1],
+                                   _core.quad_backward_ok(u, delta, B, C) and nrows == 1)
         out, x = _core.fwd_ext(u, delta, A, B, C, D, delta_bias, delta_softplus, nrows=nrows, ckpt_pitch=ctx.pitch)
         ctx.delta_softplus = delta_softplus
         ctx.save_for_backward(u, delta, A, B, C, D, delta_bias, x)

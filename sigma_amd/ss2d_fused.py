@@ -49,14 +49,23 @@ import os as _os
 _CKPT_ENV = _os.environ.get("SIGMA_CKPT_PITCH", "auto")
 
 
-def ckpt_pitch_for(seqlen: int, dstate: int = 16, rows: int = 0) -> int:
+def ckpt_pitch_for(seqlen: int, dstate: int = 16, rows: int = 0, quad_ok: bool = False) -> int:
     """Checkpoint pitch = backward tile length (include/sigma_scan.h).  Measured on MI355X
-    (profiles/r02_bwd_plans.txt): 320-element tiles win for short sequences (L = 300 pads to 320 instead
-    of 640), for 4-state scans up to 1280 elements (state-parallel backward, csrc/scan_bwd3.hip) and for
-    16-state scans up to 4800 elements when there are enough rows (batch * dim >= 12288) for the
-    row-block loop of csrc/scan_bwd2.hip to run 16-wave workgroups; 640 otherwise."""
+    (profiles/r02_bwd_plans.txt, profiles/r02_bwd4_shapes.txt):
+      * 160 (quad-row backward, csrc/scan_bwd4.hip; ``quad_ok`` = selective_scan_cuda_core.quad_backward_ok of the
+        operands) whenever there are enough rows for 12..16-wave workgroups on every CU (batch * dim >= 12288) and
+        the per-tile overhead is amortised: 8+ states, or 4 states up to 4800 elements -- 20-27 % faster than the
+        tiles below on the encoder launches;
+      * 320-element tiles for short sequences (L = 300 pads to 320 instead of 640), for 4-state scans up to 1280
+        elements (state-parallel backward, csrc/scan_bwd3.hip) and for 16-state scans up to 4800 elements with
+        enough rows for the row-block loop of csrc/scan_bwd2.hip;
+      * 640 otherwise."""
     if _CKPT_ENV != "auto":
-        return int(_CKPT_ENV)
+        forced = int(_CKPT_ENV)
+        if forced != 160 or quad_ok:
+            return forced
+    if quad_ok and rows >= 12288 and (dstate >= 8 or seqlen <= 4800):
+        return 160
     if seqlen <= 320 or (dstate <= 4 and seqlen <= 1280):
         return 320
     if dstate > 8 and seqlen <= 4800 and rows >= 12288:
@@ -198,7 +207,8 @@ class SelectiveScanExtFn(torch.autograd.Function):
         C = C.float() if C.stride(-1) == 1 else C.float().contiguous()
         A, D, delta_bias = A.float().contiguous(), D.float().contiguous(), delta_bias.float().contiguous()
         out, ck = _core.fwd_ext(u, delta, A, B, C, D, delta_bias, True, rev_mask=rev_mask, u_gshift=u_gshift,
-                                need_x=any(ctx.needs_input_grad), ckpt_pitch=ckpt_pitch_for(u.shape[-1], A.shape[1], delta.shape[0] * delta.shape[1]))
+                                need_x=any(ctx.needs_input_grad),
+                                ckpt_pitch=ckpt_pitch_for(u.shape[-1], A.shape[1], delta.shape[0] * delta.shape[1], _core.quad_backward_ok(u, delta, B, C)))
         ctx.save_for_backward(u, delta, A, B, C, D, delta_bias, ck)
         ctx.ext = (int(rev_mask), int(u_gshift))
         return out
@@ -292,8 +302,9 @@ class SS2DCoreFn(torch.autograd.Function):
         bias = dt_projs_bias.float().reshape(-1)
         Bv, Cv = p4[:, :, R:R + N], p4[:, :, R + N:]
         need_x = any(ctx.needs_input_grad)
-        out, ck = _core.fwd_ext(xs2.view(B, 2 * d, L), delta.view(B, 4 * d, L), A, Bv, Cv, Dp, bias, True,
-                                rev_mask=_REV_MASK, u_gshift=1, need_x=need_x, ckpt_pitch=ckpt_pitch_for(L, N, B * 4 * d), param_swap=1)
+        u2, dl2 = xs2.view(B, 2 * d, L), delta.view(B, 4 * d, L)
+        out, ck = _core.fwd_ext(u2, dl2, A, Bv, Cv, Dp, bias, True, rev_mask=_REV_MASK, u_gshift=1, need_x=need_x,
+                                ckpt_pitch=ckpt_pitch_for(L, N, B * 4 * d, _core.quad_backward_ok(u2, dl2, Bv, Cv)), param_swap=1)
         y = cross_merge_nhwc(out.view(B, 4, d, L), H, W)                       # (B, H, W, d)
         ctx.save_for_backward(xs2, p4, delta, A, Dp, bias, ck, Wst, dtw)
         ctx.dims = (B, d, H, W, c, R, N)

@@ -12,8 +12,18 @@ from tests.model_utils import assert_logits_close, build_model, digest, fill, lo
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture
+def force_pitch(request, monkeypatch):
+    """'auto' or a checkpoint pitch forced on every scan of the model whose operands allow it (160 = the quad-row
+    backward csrc/scan_bwd4.hip, which the automatic choice only takes for launches with >= 12288 rows)."""
+    import sigma_amd.ss2d_fused as sf
+    monkeypatch.setattr(sf, "_CKPT_ENV", request.param)
+    return request.param
+
+
+@pytest.mark.parametrize("force_pitch", ["auto", "160"], indirect=True)
 @pytest.mark.parametrize("case", ["tiny_64x96", "tiny_72x88_b2"])
-def test_logits_loss_and_grads_match_reference_fixtures(case):
+def test_logits_loss_and_grads_match_reference_fixtures(case, force_pitch):
     meta, z = load_model_golden(case)
     model = build_model(meta["backbone"], meta["num_classes"], meta["H"], meta["W"]).cuda().eval()
     rgb, x, label = fill.make_inputs(meta["batch"], meta["H"], meta["W"], meta["num_classes"])
@@ -127,8 +137,9 @@ def test_train_mode_step_and_determinism_of_forward():
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
 
 
+@pytest.mark.parametrize("force_pitch", ["auto", "160"], indirect=True)
 @pytest.mark.parametrize("shape", [(2, 24, 15, 20, 16), (1, 48, 7, 9, 4), (2, 16, 30, 40, 16), (1, 32, 12, 107, 4)])
-def test_fused_ss2d_core_equals_plain_autograd_formulation(shape):
+def test_fused_ss2d_core_equals_plain_autograd_formulation(shape, force_pitch):
     """sigma_amd.ss2d_fused (two copies of x, reversed groups by addressing, dB/dC written in place)
     against CrossScan / einsum / selective_scan_fn / CrossMerge written with plain torch ops
     (vmamba.py:165-226), values and all six gradients."""

@@ -251,11 +251,11 @@ LONG_SHAPES = [
 
 
 @pytest.mark.parametrize("shape", LONG_SHAPES, ids=["x".join(map(str, s[:5])) for s in LONG_SHAPES])
-@pytest.mark.parametrize("pitch", [0, 640, 320])
+@pytest.mark.parametrize("pitch", [0, 640, 320, 160])
 def test_long_sequences_of_the_720x1280_configuration(shape, pitch):
     """Operator-level oracle check (fwd + 7 grads) at the longest sequences the model produces, with the
     fused path's addressing (reversed groups, shared u / dout rows), for every checkpoint pitch
-    (0 = reference-shaped x / first-generation backward).  VERDICT r1 weak #1."""
+    (0 = reference-shaped x / first-generation backward, 160 = quad-row backward).  VERDICT r1 weak #1."""
     batch, KD, L, N, G, mask, ush = shape
     u, delta, A, B, C, D, bias, dout = _model_like(batch, KD, L, N, G, seed=17)
     rpg = KD // G
@@ -298,8 +298,10 @@ def test_checkpoint_tensor_shape_and_documented_layout():
     assert xf.shape == (batch, KD, 8 * N) and torch.equal(out2, out)
     out3, xq = _core().fwd_ext(*args, True, ckpt_pitch=320)
     assert xq.shape == (batch, KD, 16 * N) and torch.equal(out3, out)
-    xf, xq = xf.cpu(), xq.cpu()
-    for pitch, xt in ((1280, x), (640, xf), (320, xq)):
+    out4, xo = _core().fwd_ext(*args, True, ckpt_pitch=160)
+    assert xo.shape == (batch, KD, 32 * N) and torch.equal(out4, out)
+    xf, xq, xo = xf.cpu(), xq.cpu(), xo.cpu()
+    for pitch, xt in ((1280, x), (640, xf), (320, xq), (160, xo)):
         for j in range((L + pitch - 1) // pitch):
             end = min(L, (j + 1) * pitch)
             _, st = so.selective_scan_oracle(u[..., :end], delta[..., :end], A, B[..., :end], C[..., :end], D, bias, True,
@@ -308,7 +310,7 @@ def test_checkpoint_tensor_shape_and_documented_layout():
     # the backward gives the same gradients from either checkpoint tensor
     dout = torch.randn(batch, KD, L).to(dev)
     g1 = _core().bwd_ext(*args, dout, x.to(dev).view(batch, KD, 3, 2 * N), True)
-    for xt, pitch in ((xf, 640), (xq, 320)):
+    for xt, pitch in ((xf, 640), (xq, 320), (xo, 160)):
         g2 = _core().bwd_ext(*args, dout, xt.to(dev), True, ckpt_pitch=pitch)
         for a, b in zip(g1, g2):
             torch.testing.assert_close(a, b, rtol=2e-4, atol=1e-5 + 1e-5 * float(b.abs().max()))
@@ -424,6 +426,61 @@ def test_every_launch_geometry_is_correct(opt):
     finally:
         _capi.set_option(name, 0)
     _compare(out, grads, u, delta, A, B, C, D, bias, dout, True, torch.float32)
+
+
+QUAD_OPTS = [{}, {"bwd_sb": 1}, {"bwd_sb": 4}, {"bwd_waves": 3}, {"bwd_waves": 6, "bwd_rb": 2}, {"bwd_waves": 12}, {"bwd_waves": 16},
+             {"bwd_rb": 1}, {"bwd_touch": 2}, {"bwd_waves": 16, "bwd_sb": 1, "bwd_touch": 1}]
+
+
+@pytest.mark.parametrize("opts", QUAD_OPTS, ids=[",".join(f"{k}={v}" for k, v in o.items()) or "auto" for o in QUAD_OPTS])
+@pytest.mark.parametrize("shape", [(2, 768, 1200, 16, 4, 0b1010, 1), (2, 384, 2564, 4, 2, 0b10, 1), (3, 192, 300, 8, 1, 0, 0)],
+                         ids=["2x768x1200xN16", "2x384x2564xN4", "3x192x300xN8"])
+def test_quad_row_backward_geometries_against_oracle(shape, opts):
+    """csrc/scan_bwd4.hip (ckpt_pitch 160) in every launch geometry -- waves per workgroup, states per barrier, row
+    blocks, L2 touches on/off -- against the CPU oracle: all seven gradients, reversed groups, shared u / dout rows."""
+    batch, KD, L, N, G, mask, ush = shape
+    u, delta, A, B, C, D, bias, dout = _model_like(batch, KD, L, N, G, seed=23)
+    rpg = KD // G
+    keep = lambda t: torch.cat([t[:, g * rpg:(g + 1) * rpg] for g in range(0, G, 1 << ush)], dim=1).contiguous()
+    full = lambda t: torch.cat([t[:, (g >> ush) * rpg:((g >> ush) + 1) * rpg] for g in range(G)], dim=1)
+    u_h, g_h = keep(u), keep(dout)
+    u_f, g_f = full(u_h), full(g_h)
+    core = _core()
+    dev = "cuda"
+    args = [t.to(dev) for t in (u_h, delta, A, B, C, D, bias)]
+    assert core.quad_backward_ok(args[0], args[1], args[3], args[4])
+    out, x = core.fwd_ext(*args, True, rev_mask=mask, u_gshift=ush, ckpt_pitch=160)
+    from sigma_amd import _capi
+    try:
+        for k, v in opts.items():
+            _capi.set_option(k, v)
+        grads = core.bwd_ext(*args, g_h.to(dev), x, True, rev_mask=mask, u_gshift=ush, dout_gshift=ush, ckpt_pitch=160)
+    finally:
+        for k in opts:
+            _capi.set_option(k, 0)
+    revs = [(mask >> g) & 1 for g in range(G)]
+    fr = lambda t: torch.cat([t[:, g * rpg:(g + 1) * rpg].flip(-1) if revs[g] else t[:, g * rpg:(g + 1) * rpg] for g in range(G)], 1)
+    fg = lambda t: torch.stack([t[:, g].flip(-1) if revs[g] else t[:, g] for g in range(G)], 1)
+    so = _oracle()
+    rg = list(so.selective_scan_oracle_bwd(fr(u_f), fr(delta), A, fg(B), fg(C), D, bias, fr(g_f), True))
+    rg[0], rg[1], rg[3], rg[4] = fr(rg[0]), fr(rg[1]), fg(rg[3]), fg(rg[4])
+    for name, g, r in zip(["u", "delta", "A", "B", "C", "D", "bias"], grads, rg):
+        torch.testing.assert_close(g.cpu(), r, rtol=3e-3, atol=2e-3 + 2e-4 * float(r.abs().max()),
+                                   msg=lambda m, name=name: f"d{name}: {m}")
+
+
+def test_quad_row_backward_refuses_what_it_cannot_take():
+    """ckpt_pitch 160 with 16-bit IO / odd lengths must fail loudly (no silent fallback), and quad_backward_ok says so first."""
+    core = _core()
+    dev = "cuda"
+    u, delta, A, B, C, D, bias, dout = _model_like(1, 16, 322, 4, 2, seed=1)
+    args = [t.to(dev) for t in (u, delta, A, B, C, D, bias)]
+    assert not core.quad_backward_ok(args[0], args[1], args[3], args[4])          # L % 4 != 0
+    out, x = core.fwd_ext(*args, True, ckpt_pitch=160)                          # the forward takes any pitch
+    with pytest.raises(RuntimeError, match="ckpt_pitch 160"):
+        core.bwd_ext(*args, dout.to(dev), x, True, ckpt_pitch=160)
+    h = [t.to(dev).half() if i in (0, 1, 3, 4) else t.to(dev) for i, t in enumerate(_model_like(1, 16, 320, 4, 2, seed=1)[:7])]
+    assert not core.quad_backward_ok(h[0], h[1], h[3], h[4])
 
 
 def test_error_behaviour_matches_reference_checks():

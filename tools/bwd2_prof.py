@@ -28,6 +28,8 @@ def main():
     variants = [("T10 rb1", 640, dict(bwd_gen=2, bwd_rb=1)), ("T10 auto", 640, dict(bwd_gen=2)),
                 ("T10 R16", 640, dict(bwd_gen=2, bwd_waves=16, bwd_nb=2)), ("T5 R16", 320, dict(bwd_gen=2, bwd_waves=16)),
                 ("T5 R8 rb1", 320, dict(bwd_gen=2, bwd_waves=8, bwd_rb=1))]
+    if os.environ.get("VARIANTS"):       # JSON [[label, pitch, {option: value}], ...]
+        variants = [tuple(v) for v in json.loads(os.environ["VARIANTS"])]
     for name in sys.argv[1:] or ["enc_s2_b16", "dec_s0_b8"]:
         shape = SHAPES[name]
         u, delta, A, Bm, Cm, D, bias, dout = make(shape)

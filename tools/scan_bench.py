@@ -104,7 +104,7 @@ def main():
         pitch = 0
         if a.fine:
             from sigma_amd.ss2d_fused import ckpt_pitch_for
-            pitch = ckpt_pitch_for(shape[2], shape[3], shape[0] * shape[1])
+            pitch = ckpt_pitch_for(shape[2], shape[3], shape[0] * shape[1], core.quad_backward_ok(u, delta, Bm, Cm))
             _, x = core.fwd_ext(u, delta, A, Bm, Cm, D, bias, True, ckpt_pitch=pitch)
         else:
             _, x = core.fwd(u, delta, A, Bm, Cm, D, bias, True, 1)
