@@ -20,7 +20,7 @@ thread_local std::string g_err;
 
 std::atomic<int> g_opt_fwd_items{0}, g_opt_fwd_waves{0}, g_opt_fwd_tiles{0}, g_opt_fwd_nb{0};
 std::atomic<int> g_opt_bwd_items{0}, g_opt_bwd_waves{0}, g_opt_bwd_nb{0}, g_opt_no_glds{0}, g_opt_bwd_slab2{0}, g_opt_fwd_prefetch{0};
-std::atomic<int> g_opt_bwd_gen{0}, g_opt_bwd_rb{0}, g_opt_bwd_touch{0}, g_opt_bwd_sb{0};
+std::atomic<int> g_opt_bwd_gen{0}, g_opt_bwd_rb{0}, g_opt_bwd_touch{0}, g_opt_bwd_sb{0}, g_opt_bwd_wgs{0};
 
 int fail(int code, const char* fmt, ...) {
     char buf[512];
@@ -363,7 +363,7 @@ Plan3 plan_bwd3(const sigma_scan_fwd_params* p, bool vec) {
 
 // scan_bwd4 (scan_bwd4.hip): quad-row mapping, 160-position tiles; a workgroup is W waves x 4 rows and walks RB
 // row blocks per tile; P = rows_per_group / (4 * W * RB) workgroups share a group; SB states share a barrier.
-struct Plan4 { bool ok; int W, RB, SB, P, grid; size_t lds; };
+struct Plan4 { bool ok; int W, RB, SB, P, grid, nbuf, wgs; size_t lds; };
 
 Plan4 plan_bwd4(const sigma_scan_fwd_params* p, bool vec) {
     Plan4 pl;
@@ -381,11 +381,14 @@ Plan4 plan_bwd4(const sigma_scan_fwd_params* p, bool vec) {
     // workgroup size (B/C staging, barriers and column sums are per-workgroup costs; 16 waves = four per SIMD in
     // the 128-VGPR build): measured on (16,3072,1200,N16) 918 / 979 / 1185 us for W = 16 / 12 / 8 at equal grids
     // (profiles/r02_bwd4_shapes.txt).  Ties go to more row blocks (fewer partial dB/dC slabs).
+    // "bwd_wgs" = 2: two workgroups of <= 8 waves per CU (<= 80 KB LDS each: one B/C image, one state per barrier).
     const int frb = g_opt_bwd_rb.load();
+    const int wgs = g_opt_bwd_wgs.load() == 2 ? 2 : 1;
+    const long slots = (long)kCUs * wgs;
     const long bg = (long)p->batch * p->n_groups;
     int W = 0, RB = 1;
     double best = 1e300;
-    for (int w = 16; w >= 1; --w) {
+    for (int w = wgs == 2 ? 8 : 16; w >= 1; --w) {
         if (quads % w != 0) continue;
         if (fr > 0 && fr <= 16 && quads % fr == 0 && w != fr) continue;          // forced waves (when legal)
         const int rowblocks_w = quads / w;
@@ -396,26 +399,31 @@ Plan4 plan_bwd4(const sigma_scan_fwd_params* p, bool vec) {
                 while (want > 1 && rowblocks_w % want != 0) --want;
                 if (d != want) continue;
             }
-            if ((size_t)d * 4 * w * N * sizeof(float) > 48 * 1024) continue;     // reverse carries of the chunk's rows
+            if ((size_t)d * 4 * w * N * sizeof(float) > (wgs == 2 ? 8u : 24u) * 1024) continue;   // reverse carries of the chunk's rows
             const long grid = bg * (rowblocks_w / d);
-            const double rounds = (double)((grid + kCUs - 1) / kCUs);
+            const double rounds = (double)((grid + slots - 1) / slots);
             const double cost = rounds * d * w * (0.73 + 4.3 / w);
             if (cost < best * 0.999) { best = cost; W = w; RB = d; }
         }
     }
     if (W == 0) return pl;
     const int rowblocks = quads / W;
-    int SB = g_opt_bwd_sb.load() > 0 ? g_opt_bwd_sb.load() : 2;
+    const size_t lds_limit = wgs == 2 ? kLdsLimit / 2 : kLdsLimit;
+    int nbuf = (wgs == 2 || g_opt_bwd_nb.load() == 1) ? 1 : 2;       // "bwd_nb" = 1: one B/C image
+    int SB = g_opt_bwd_sb.load() > 0 ? g_opt_bwd_sb.load() : (wgs == 2 ? 1 : 2);
     while (SB > 1 && N % SB != 0) SB >>= 1;
-    while (sigma::bwd4_lds_bytes(W, N, SB, RB) > kLdsLimit) {
-        if (SB > 1) SB >>= 1;
+    while (sigma::bwd4_lds_bytes(W, N, SB, RB, nbuf) > lds_limit) {
+        if (SB > 2) SB >>= 1;
+        else if (nbuf > 1) nbuf = 1;                                 // measured: the second image buys 3 %, SB = 2 buys 5 %
+        else if (SB > 1) SB >>= 1;
         else if (RB > 1) { --RB; while (RB > 1 && rowblocks % RB != 0) --RB; }
         else return pl;
     }
+    pl.nbuf = nbuf; pl.wgs = wgs;
     pl.ok = true;
     pl.W = W; pl.RB = RB; pl.SB = SB; pl.P = rowblocks / RB;
     pl.grid = p->batch * p->n_groups * pl.P;
-    pl.lds = sigma::bwd4_lds_bytes(W, N, SB, RB);
+    pl.lds = sigma::bwd4_lds_bytes(W, N, SB, RB, nbuf);
     return pl;
 }
 
@@ -441,6 +449,7 @@ OptDesc g_opts[] = {
     {"bwd_slab2", &g_opt_bwd_slab2, {0, 1, 2, -1}},        // 1 = two dB/dC slab sets when they fit
     {"fwd_prefetch", &g_opt_fwd_prefetch, {0, 1, 2, -1}},  // 2 = no register prefetch of the next tile's u/delta (T = 10)
     {"bwd_gen", &g_opt_bwd_gen, {0, 1, 2, 3, -1}},         // backward kernel: 1 = scan_bwd.hip, 2 = scan_bwd2.hip, 3 / 0 = best legal
+    {"bwd_wgs", &g_opt_bwd_wgs, {0, 1, 2, -1}},              // quad-row backward: 2 = two small workgroups per CU
     {"bwd_sb", &g_opt_bwd_sb, {0, 1, 2, 4, 8, -1}},          // quad-row backward: states per barrier (0 = 2)
     {"bwd_touch", &g_opt_bwd_touch, {0, 1, 2, -1}},   // L2 warm-up touches of the next row step: 1 = on, 2 = off, 0 = on in scan_bwd4 only
     {"bwd_rb", &g_opt_bwd_rb, {-3}},                       // scan_bwd2: row blocks per workgroup, 0..256
@@ -618,7 +627,7 @@ int sigma_selective_scan_bwd(const sigma_scan_bwd_params* q, void* stream) {
         a.flags = (t == 1 || (t == 0 && p4.ok)) ? 0 : 1;
     }
     a.RB = p4.ok ? p4.RB : p3.ok ? p3.RB : (p2.ok ? p2.RB : 1);
-    if (p4.ok) a.slab2 = p4.SB;
+    if (p4.ok) { a.slab2 = p4.SB; a.f.NB = p4.nbuf; if (p4.wgs == 2) a.flags |= 2; }
     hipError_t e = p4.ok ? sigma::launch_scan_bwd4(a, static_cast<hipStream_t>(stream)) : p3.ok ? sigma::launch_scan_bwd3(a, p->io_dtype, pl.glds, static_cast<hipStream_t>(stream)) : p2.ok ? sigma::launch_scan_bwd2(a, p->io_dtype, pl.items, pl.glds, static_cast<hipStream_t>(stream))
                          : sigma::launch_scan_bwd(a, p->io_dtype, pl.items, pl.glds, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(SIGMA_ERR_LAUNCH, "scan_bwd launch failed: %s", hipGetErrorString(e));

@@ -233,7 +233,9 @@ __device__ __forceinline__ void scan_bwd4_body(const BwdArgs& q, float* smem, in
     const int SB = q.slab2;                           // states per barrier; 2*SB slab sets
     const int bufsz = 2 * N * kTile4;
     float* sBC = smem;                                // [2][2][N][160]
-    float* sRed = sBC + 2 * bufsz;                    // [2*SB][W][320] four-row sums of the dB/dC terms
+    const int nbuf = p.NB;                            // B/C images: 2 = the next tile streams in during this one,
+                                                      // 1 = it streams in during the last column sums + row epilogue
+    float* sRed = sBC + nbuf * bufsz;                 // [2*SB][W][320] four-row sums of the dB/dC terms
     float* sRv = sRed + 2 * SB * W * kCols4;          // [RB*4*W][N] reverse carry a*dx of the tile to the right
     float* sSink = sRv + RB * 4 * W * N;              // 64 floats: target of the L2 warm-up touches
     float* sAcc = sSink + 64;                         // [N][320] when RB > 1
@@ -264,7 +266,7 @@ __device__ __forceinline__ void scan_bwd4_body(const BwdArgs& q, float* smem, in
 
     for (int i = tid; i < RB * 4 * W * N; i += blockDim.x) sRv[i] = 0.0f;
     // never multiply uninitialised LDS bits (stale/NaN) into the padding of the last tile
-    for (int i = tid; i < 2 * bufsz / 4; i += blockDim.x) reinterpret_cast<float4*>(sBC)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = tid; i < nbuf * bufsz / 4; i += blockDim.x) reinterpret_cast<float4*>(sBC)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
 
     const int ntiles = (L + kTile4 - 1) / kTile4;
@@ -272,18 +274,20 @@ __device__ __forceinline__ void scan_bwd4_body(const BwdArgs& q, float* smem, in
         stage_tile4<REV>(sBC + buf * bufsz, Bg, Cg, (int)p.B_ns, (int)p.C_ns, N, tile, L);
     };
 
-    // column c of a state's 320: register m = c / 64 of lane c % 64: DPP row rr = (c % 64) / 16 holds
-    // {dB pos 2m, dB pos 2m+1, dC pos 2m, dC pos 2m+1}[rr] of the 10 positions of lane (c % 16) -- see fold16.
-    // Column-sum threads: with S = threads / 320 >= 1, thread t < 320*S owns column t % 320 of the states
-    // t / 320, t / 320 + S, ... of a state group (its position inside the tile is computed once); smaller
+    // Slab layout: column c of a state's 320 = array (c / 160: dB, dC) x tile position (c % 160).  After fold16
+    // register m of a lane holds {dB pos 2m, dB pos 2m+1, dC pos 2m, dC pos 2m+1}[DPP row] of the 10 positions of
+    // lane li, so the lane writes it to column slab_c0 + 2m (bank-conflict free: lane stride 10 dwords, the four
+    // rows land 0 / 1 / 160 / 161 apart).  Column-sum threads: with S = threads / 320 >= 1, thread t < 320*S owns
+    // column t % 320 of the states t / 320, t / 320 + S, ... of a state group -- consecutive threads own
+    // consecutive memory positions, so the dB/dC stores of a wave are one contiguous 256-byte piece; smaller
     // workgroups loop over the columns as well.
+    const int slab_c0 = (qr >> 1) * kTile4 + li * T + (qr & 1);
     const int colS = (int)blockDim.x / kCols4;
     const int col_c = tid % kCols4;
     const int col_s0 = tid / kCols4;
     auto col_pos = [&](int c, bool& is_c) {
-        const int m = c >> 6, cl = c & 63, rr = cl >> 4, cli = cl & 15;
-        is_c = rr >= 2;
-        return cli * T + 2 * m + (rr & 1);
+        is_c = c >= kTile4;
+        return is_c ? c - kTile4 : c;
     };
     bool my_is_c;
     const int my_pos = col_pos(col_c, my_is_c);
@@ -306,10 +310,14 @@ __device__ __forceinline__ void scan_bwd4_body(const BwdArgs& q, float* smem, in
 
     for (int j = ntiles - 1; j >= 0; --j) {
         const int l0 = j * kTile4;
-        const int lbase = l0 + li * T;
+        const int lbase_t = l0 + li * T;
         const float* cur = sBC + buf * bufsz;
-        if (j > 0) stage(buf ^ 1, j - 1);              // lands while this tile is processed
+        if (nbuf == 2 && j > 0) stage(buf ^ 1, j - 1); // lands while this tile is processed
         for (int rb = 0; rb < RB; ++rb) {
+            // laundered per row step: the ten load offsets derived from lbase are row-step invariant, and hoisted out
+            // of this loop they lived in scratch in the 128-VGPR build (30 reloads of 512 B per wave and row step)
+            int lbase = lbase_t;
+            asm volatile("" : "+v"(lbase));
             const int rl = (rb * W + wave) * 4 + qr;   // row inside the chunk (per DPP row)
             const int r = row_c0 + rl;
             cold4_t kq = cold_args4();
@@ -351,6 +359,8 @@ __device__ __forceinline__ void scan_bwd4_body(const BwdArgs& q, float* smem, in
             float dsum = 0.0f;
 #pragma unroll
             for (int k = 0; k < T; ++k) dsum += dl[k];
+            // dA / dD / ddelta_bias leave through one atomicAdd per (row, tile) and state.  Summing them over the
+            // tiles in LDS first (measured: WRITE_SIZE -6 %) costs the second B/C image its LDS and 3 % run time.
             if (kq->dD) { dD_acc = row_sum_to_lane0(dD_acc); if (li0) atomicAdd(kq->dD + pr, dD_acc); }
 
             PROF(1)                                            // row prologue: loads, softplus
@@ -426,7 +436,7 @@ __device__ __forceinline__ void scan_bwd4_body(const BwdArgs& q, float* smem, in
                 float dAp = 0.0f;
                 PROF(4)                                        // reverse fold + scan
                 const int sidx = ((grp & 1) * SB + (n % SB)) * W + wave;
-                float* __restrict__ slab = sRed + sidx * kCols4 + lane;
+                float* __restrict__ slab = sRed + sidx * kCols4 + slab_c0;
 #pragma unroll
                 for (int qq = T / 2 - 1; qq >= 0; --qq) {
                     float bq[2], vb[2], vc[2];
@@ -444,7 +454,7 @@ __device__ __forceinline__ void scan_bwd4_body(const BwdArgs& q, float* smem, in
                         vc[jj] = gg[k] * xs[k];                  // this row's term of dC[n, l]
                     }
                     // four-row sums: rows of the result = {dB pos 2qq, dB pos 2qq+1, dC pos 2qq, dC pos 2qq+1}
-                    slab[qq * 64] = fold16(fold32(vb[0], vc[0]), fold32(vb[1], vc[1]));
+                    slab[2 * qq] = fold16(fold32(vb[0], vc[0]), fold32(vb[1], vc[1]));
                 }
                 // collect: lane 0 of each row holds the result of this state; select + rotate, so that after
                 // N states the value of state n sits in lane 16 - N + n
@@ -454,7 +464,12 @@ __device__ __forceinline__ void scan_bwd4_body(const BwdArgs& q, float* smem, in
                 PROF(5)                                        // reverse replay, four-row sums, slab writes, collect
                 if ((n % SB) == SB - 1) {
                     // slabs of this state group complete; at the end of the tile also "next B/C image landed"
-                    if (n == N - 1 && rb == RB - 1) { lds_dma_wait(); __syncthreads(); } else lds_barrier();
+                    if (n == N - 1 && rb == RB - 1) {
+                        if (nbuf == 2) { lds_dma_wait(); __syncthreads(); }
+                        else { lds_barrier(); if (j > 0) stage(0, j - 1); }      // every wave is done with this tile's image
+                    } else {
+                        lds_barrier();
+                    }
                     PROF(6)                                    // barrier wait
                     const float* sset = sRed + ((grp & 1) * SB) * W * kCols4;
                     auto column = [&](int s, int c, int pos, bool is_c) {
@@ -558,7 +573,8 @@ __device__ __forceinline__ void scan_bwd4_body(const BwdArgs& q, float* smem, in
             if (ke->dbias) { dbias_acc = row_sum_to_lane0(dbias_acc); if (li_e == 0) atomicAdd(ke->dbias + pr_e, dbias_acc); }
             PROF(8)                                            // row epilogue
         }
-        buf ^= 1;
+        if (nbuf == 2) buf ^= 1;
+        else if (j > 0) { lds_dma_wait(); __syncthreads(); }
     }
     PROF_FLUSH
 }
@@ -580,7 +596,7 @@ scan_bwd4_kernel(const BwdArgs q) {
 // a.f.R = waves per workgroup (4 rows each), a.slab2 = states per barrier, a.RB = row blocks per workgroup
 template <int MAXW>
 static hipError_t launch_bwd4_t(const BwdArgs& a, hipStream_t stream) {
-    const size_t lds = bwd4_lds_bytes(a.f.R, a.f.N, a.slab2, a.RB);
+    const size_t lds = bwd4_lds_bytes(a.f.R, a.f.N, a.slab2, a.RB, a.f.NB);
     const int grid = a.f.batch * a.f.G * a.P;
     auto kern = scan_bwd4_kernel<MAXW>;
     static std::atomic<size_t> lds_cap[kMaxDevices];
@@ -600,8 +616,9 @@ static hipError_t launch_bwd4_t(const BwdArgs& a, hipStream_t stream) {
 }
 
 hipError_t launch_scan_bwd4(const BwdArgs& a, hipStream_t stream) {
-    // up to 12 waves: ~150 VGPRs, 3 waves per SIMD; 13..16 waves: the 128-VGPR build
-    return a.f.R > 12 ? launch_bwd4_t<16>(a, stream) : launch_bwd4_t<12>(a, stream);
+    // up to 12 waves: ~150 VGPRs, 3 waves per SIMD; 13..16 waves -- or two workgroups per CU (flags bit 1): the
+    // 128-VGPR build
+    return (a.f.R > 12 || (a.flags & 2)) ? launch_bwd4_t<16>(a, stream) : launch_bwd4_t<12>(a, stream);
 }
 
 }  // namespace sigma

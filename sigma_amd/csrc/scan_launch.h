@@ -42,10 +42,10 @@ inline size_t bwd3_lds_bytes(int nw, int N, int RB) {
     return sizeof(float) * (2 * (size_t)N * tile + 4 * (size_t)nw * tile + (size_t)RB * (nw / Q) * N);
 }
 
-// scan_bwd4 (quad-row): B/C image of one 160-tile for all states, double-buffered [2][2][N][160] + 2*SB slab
-// sets [W][320] + reverse carries of the chunk's RB*4*W rows + the dB/dC accumulators [N][320] when RB > 1
-inline size_t bwd4_lds_bytes(int W, int N, int SB, int RB) {
-    return sizeof(float) * (2 * 2 * (size_t)N * 160 + 2 * (size_t)SB * W * 320 + (size_t)RB * 4 * W * N + 64 + (RB > 1 ? (size_t)N * 320 : 0));
+// scan_bwd4 (quad-row): nbuf B/C images of one 160-tile for all states [nbuf][2][N][160] + 2*SB slab sets [W][320]
+// + reverse carries [RB*4*W][N] + touch sink + the dB/dC accumulators [N][320] when RB > 1
+inline size_t bwd4_lds_bytes(int W, int N, int SB, int RB, int nbuf = 2) {
+    return sizeof(float) * ((size_t)nbuf * 2 * (size_t)N * 160 + 2 * (size_t)SB * W * 320 + (size_t)RB * 4 * W * N + 64 + (RB > 1 ? (size_t)N * 320 : 0));
 }
 
 constexpr int kMaxDevices = 16;    // per-device cache of the raised dynamic-LDS cap (hipFuncSetAttribute is per device)
