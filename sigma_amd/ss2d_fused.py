@@ -53,9 +53,9 @@ def ckpt_pitch_for(seqlen: int, dstate: int = 16, rows: int = 0, quad_ok: bool =
     """Checkpoint pitch = backward tile length (include/sigma_scan.h).  Measured on MI355X
     (profiles/r02_bwd_plans.txt, profiles/r02_bwd4_shapes.txt):
       * 160 (quad-row backward, csrc/scan_bwd4.hip; ``quad_ok`` = selective_scan_cuda_core.quad_backward_ok of the
-        operands) whenever there are enough rows for 12..16-wave workgroups on every CU (batch * dim >= 12288) and
-        the per-tile overhead is amortised: 8+ states, or 4 states up to 4800 elements -- 20-27 % faster than the
-        tiles below on the encoder launches;
+        operands) whenever there are enough rows for workgroups of 8+ waves on every CU (batch * dim >= 8192 with
+        8+ states; >= 12288 with 4 states up to 4800 elements, where the per-tile overhead weighs more) -- 8-27 %
+        faster than the tiles below on the encoder launches (profiles/r02_bwd4_shapes.txt, r02_bwd4_mid.txt);
       * 320-element tiles for short sequences (L = 300 pads to 320 instead of 640), for 4-state scans up to 1280
         elements (state-parallel backward, csrc/scan_bwd3.hip) and for 16-state scans up to 4800 elements with
         enough rows for the row-block loop of csrc/scan_bwd2.hip;
@@ -64,7 +64,7 @@ def ckpt_pitch_for(seqlen: int, dstate: int = 16, rows: int = 0, quad_ok: bool =
         forced = int(_CKPT_ENV)
         if forced != 160 or quad_ok:
             return forced
-    if quad_ok and rows >= 12288 and (dstate >= 8 or seqlen <= 4800):
+    if quad_ok and ((dstate >= 8 and rows >= 8192) or (rows >= 12288 and seqlen <= 4800)):
         return 160
     if seqlen <= 320 or (dstate <= 4 and seqlen <= 1280):
         return 320

@@ -41,6 +41,13 @@ SHAPES = {
     "enc_s1_b16": (16, 1536, 4800, 16, 4),
     "enc_s2_b16": (16, 3072, 1200, 16, 4),
     "enc_s3_b16": (16, 6144, 300, 16, 4),
+    # sigma_base @720x1280, batch 1 (BASELINE configs[4]): both modalities stacked
+    "base_s0_b2": (2, 1024, 57600, 16, 4),
+    "base_s1_b2": (2, 2048, 14400, 16, 4),
+    "base_s2_b2": (2, 4096, 3600, 16, 4),
+    "base_s3_b2": (2, 8192, 900, 16, 4),
+    "enc_s0_b2": (2, 768, 19200, 16, 4),
+    "enc_s2_b2": (2, 3072, 1200, 16, 4),
 }
 
 HBM_PEAK = 8.0e12
