@@ -60,6 +60,9 @@ def parse():
     ap.add_argument("--graph", action="store_true",
                     help="capture the step (fwd + bwd + AdamW) as one HIP graph and time replays (single process); the "
                          "roofline object then comes from a few eager steps run before the capture")
+    ap.add_argument("--split-gemm", action="store_true",
+                    help="nn.Linear GEMMs as split-operand bf16 MFMA GEMMs (sigma_amd/split_linear.py: 4e-6 rms error per GEMM, "
+                         "reported as config.gemm; the default and headline stay fp32 GEMMs)")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="(unused: the CPU sample is fixed) kept for compatibility")
     ap.add_argument("--kernel-report", default="", help="write the per-kernel-shape table (json) here")
     return ap.parse_args()
@@ -216,6 +219,8 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
 
+    if a.split_gemm:
+        os.environ["SIGMA_SPLIT_GEMM"] = "1"
     from sigma_amd import selective_scan_cuda_core as core
     from sigma_amd.models.builder import EncoderDecoder
 
@@ -307,6 +312,7 @@ def main():
                     config=dict(workload=f"{a.backbone} training step (fwd+bwd+AdamW), RGB-X pairs {a.height}x{a.width}, "
                                          f"{a.classes} classes, fp32", per_gpu_batch=a.batch,
                                 global_batch=a.batch * world, parallelism=f"dp{world}", hip_graph=use_graph,
+                                gemm=("bf16x3 split-operand MFMA, fp32 accumulate/output" if a.split_gemm else "fp32"),
                                 loss=round(float(loss.item()), 4)),
                     roofline=roof, roofline_fwd=roof_fwd, cpu_baseline=cpu)
         print(json.dumps(line), flush=True)

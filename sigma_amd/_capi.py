@@ -111,7 +111,7 @@ class LayerNormParams(ctypes.Structure):
 # every symbol include/sigma_ops.h declares
 OPS_SYMBOLS = ("sigma_dwconv3x3_silu_fwd", "sigma_dwconv3x3_silu_bwd", "sigma_cross_merge_nhwc", "sigma_cross_split_nhwc",
                "sigma_layernorm_fwd", "sigma_layernorm_bwd", "sigma_layernorm_bwd_partial_rows", "sigma_transpose2d",
-               "sigma_pair_sum_add")
+               "sigma_pair_sum_add", "sigma_split_bf16")
 
 # every symbol include/sigma_scan.h declares; tests check the library exports all of them
 EXPORTED_SYMBOLS = (
@@ -173,6 +173,9 @@ def load() -> ctypes.CDLL:
             fn.argtypes = [ctypes.c_int64]
         elif name == "sigma_pair_sum_add":
             fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]
+        elif name == "sigma_split_bf16":
+            fn.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
+                           ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]
         else:
             st = (MergeParams if "cross_" in name else LayerNormParams if "layernorm" in name else
                   TransposeParams if "transpose" in name else DwConvParams)

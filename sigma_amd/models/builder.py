@@ -65,6 +65,9 @@ class EncoderDecoder(nn.Module):
         self.criterion = criterion
         if self.criterion:
             self.init_weights(cfg, pretrained=getattr(cfg, "pretrained_model", None))
+        # opt-in: nn.Linear GEMMs as split-operand bf16 MFMA GEMMs (sigma_amd/split_linear.py; SIGMA_SPLIT_GEMM=1)
+        from ..split_linear import enable_split_linears, split_gemm_requested
+        self.split_linears = enable_split_linears(self) if split_gemm_requested() else 0
 
     def init_weights(self, cfg, pretrained=None):
         if pretrained:
