@@ -184,6 +184,7 @@ int sigma_scan_abi_version(void);
  *   "bwd_touch"                L2 warm-up of the next row step's u/delta/dout lines: 1 = on, 2 = off, 0 = on in the
  *                              quad-row backward (touches 3 states ahead: -3..-6 %), off in the second generation (there
  *                              a whole row step ahead: every line fetched twice for 1 %, profiles/r02_pmc_enc_s2_b16.txt)
+ *   "fwd_gen"                  1 = never the quad-row forward (scan_fwd4.hip), which serves ckpt_pitch 160 otherwise
  *   "bwd_sb"                   quad-row backward (ckpt_pitch 160): states per barrier {1, 2, 4, 8}; 0 = 2
  * Returns SIGMA_ERR_BAD_OPTION for unknown names / unsupported values. */
 int sigma_scan_set_option(const char *name, int value);

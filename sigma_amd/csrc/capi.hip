@@ -20,7 +20,7 @@ thread_local std::string g_err;
 
 std::atomic<int> g_opt_fwd_items{0}, g_opt_fwd_waves{0}, g_opt_fwd_tiles{0}, g_opt_fwd_nb{0};
 std::atomic<int> g_opt_bwd_items{0}, g_opt_bwd_waves{0}, g_opt_bwd_nb{0}, g_opt_no_glds{0}, g_opt_bwd_slab2{0}, g_opt_fwd_prefetch{0};
-std::atomic<int> g_opt_bwd_gen{0}, g_opt_bwd_rb{0}, g_opt_bwd_touch{0}, g_opt_bwd_sb{0}, g_opt_bwd_wgs{0};
+std::atomic<int> g_opt_bwd_gen{0}, g_opt_bwd_rb{0}, g_opt_bwd_touch{0}, g_opt_bwd_sb{0}, g_opt_bwd_wgs{0}, g_opt_fwd_gen{0};
 
 int fail(int code, const char* fmt, ...) {
     char buf[512];
@@ -361,6 +361,36 @@ Plan3 plan_bwd3(const sigma_scan_fwd_params* p, bool vec) {
     return pl;
 }
 
+// scan_fwd4 (scan_fwd4.hip): quad-row forward for ckpt_pitch 160; a workgroup is W <= 8 waves x 4 rows of one
+// (batch, group) sharing the B/C image of a tile.  Two 8-wave workgroups per CU (41 KB LDS each at N = 16).
+struct PlanF4 { bool ok; int W, P, grid; size_t lds; };
+
+PlanF4 plan_fwd4(const sigma_scan_fwd_params* p, bool vec) {
+    PlanF4 pl;
+    std::memset(&pl, 0, sizeof(pl));
+    if (p->ckpt_pitch != SIGMA_SCAN_CKPT_PITCH_160 || g_opt_fwd_gen.load() == 1) return pl;
+    const int N = p->dstate;
+    if (N != 2 && N != 4 && N != 8 && N != 16) return pl;
+    if (!glds_ok(p, vec)) return pl;
+    const int rpg = p->dim / p->n_groups;
+    if (rpg % 4 != 0) return pl;
+    const int quads = rpg / 4;
+    const int fr = g_opt_fwd_waves.load();
+    const long bg = (long)p->batch * p->n_groups;
+    int W = 0;
+    if (fr > 0 && fr <= 8 && quads % fr == 0) W = fr;
+    for (int w = 8; W == 0 && w >= 1; --w) {
+        if (quads % w != 0) continue;
+        if (bg * (quads / w) >= 2 * kCUs || w == 1) W = w;               // two workgroups per CU wanted
+    }
+    if (W == 0) return pl;
+    pl.ok = true;
+    pl.W = W; pl.P = quads / W;
+    pl.grid = (int)(bg * pl.P);
+    pl.lds = sigma::fwd4_lds_bytes(N);
+    return pl;
+}
+
 // scan_bwd4 (scan_bwd4.hip): quad-row mapping, 160-position tiles; a workgroup is W waves x 4 rows and walks RB
 // row blocks per tile; P = rows_per_group / (4 * W * RB) workgroups share a group; SB states share a barrier.
 struct Plan4 { bool ok; int W, RB, SB, P, grid, nbuf, wgs; size_t lds; };
@@ -449,6 +479,7 @@ OptDesc g_opts[] = {
     {"bwd_slab2", &g_opt_bwd_slab2, {0, 1, 2, -1}},        // 1 = two dB/dC slab sets when they fit
     {"fwd_prefetch", &g_opt_fwd_prefetch, {0, 1, 2, -1}},  // 2 = no register prefetch of the next tile's u/delta (T = 10)
     {"bwd_gen", &g_opt_bwd_gen, {0, 1, 2, 3, -1}},         // backward kernel: 1 = scan_bwd.hip, 2 = scan_bwd2.hip, 3 / 0 = best legal
+    {"fwd_gen", &g_opt_fwd_gen, {0, 1, -1}},                 // 1 = never the quad-row forward (scan_fwd4.hip)
     {"bwd_wgs", &g_opt_bwd_wgs, {0, 1, 2, -1}},              // quad-row backward: 2 = two small workgroups per CU
     {"bwd_sb", &g_opt_bwd_sb, {0, 1, 2, 4, 8, -1}},          // quad-row backward: states per barrier (0 = 2)
     {"bwd_touch", &g_opt_bwd_touch, {0, 1, 2, -1}},   // L2 warm-up touches of the next row step: 1 = on, 2 = off, 0 = on in scan_bwd4 only
@@ -481,6 +512,11 @@ int sigma_scan_fwd_plan(const sigma_scan_fwd_params* p, int32_t plan[6]) {
     int rc = check_fwd(p, false, false);
     if (rc) return rc;
     if (!plan) return fail(SIGMA_ERR_NULL_ARG, "plan is NULL");
+    const PlanF4 p4 = plan_fwd4(p, true);
+    if (p4.ok) {      // quad-row forward: items 10, rows slot = waves (4 rows each), states_per_block slot = -100
+        plan[0] = 10; plan[1] = p4.W; plan[2] = p4.grid; plan[3] = (int32_t)p4.lds; plan[4] = 1; plan[5] = -100;
+        return SIGMA_OK;
+    }
     Plan pl = plan_fwd(p, true);
     plan[0] = pl.items; plan[1] = pl.rows; plan[2] = pl.grid; plan[3] = (int32_t)pl.lds; plan[4] = pl.tiles; plan[5] = pl.nb;
     return SIGMA_OK;
@@ -518,6 +554,14 @@ int sigma_selective_scan_fwd(const sigma_scan_fwd_params* p, void* stream) {
     if (rc) return rc;
     if (p->batch == 0 || p->seqlen == 0) return SIGMA_OK;
     const bool vec = vec_ok_fwd(p, true) && (p->rev_group_mask == 0 || p->seqlen % 4 == 0);
+    const PlanF4 p4 = plan_fwd4(p, vec);
+    if (p4.ok) {
+        sigma::FwdArgs a = make_fwd_args(p, p4.W, 1, p->dstate, vec);
+        a.rowblocks = p4.P;
+        hipError_t e = sigma::launch_scan_fwd4(a, static_cast<hipStream_t>(stream));
+        if (e != hipSuccess) return fail(SIGMA_ERR_LAUNCH, "scan_fwd4 launch failed: %s", hipGetErrorString(e));
+        return SIGMA_OK;
+    }
     const Plan pl = plan_fwd(p, vec);
     if (pl.lds > kLdsLimit) return fail(SIGMA_ERR_BAD_SHAPE, "LDS budget exceeded (%zu B)", pl.lds);
     const sigma::FwdArgs a = make_fwd_args(p, pl.rows, pl.tiles, pl.nb, vec);

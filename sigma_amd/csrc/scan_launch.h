@@ -48,10 +48,14 @@ inline size_t bwd4_lds_bytes(int W, int N, int SB, int RB, int nbuf = 2) {
     return sizeof(float) * ((size_t)nbuf * 2 * (size_t)N * 160 + 2 * (size_t)SB * W * 320 + (size_t)RB * 4 * W * N + 64 + (RB > 1 ? (size_t)N * 320 : 0));
 }
 
+// scan_fwd4 (quad-row forward): two B/C images of one 160-tile for all states [2][2][N][160]
+inline size_t fwd4_lds_bytes(int N) { return sizeof(float) * (2 * 2 * (size_t)N * 160); }
+
 constexpr int kMaxDevices = 16;    // per-device cache of the raised dynamic-LDS cap (hipFuncSetAttribute is per device)
 
 hipError_t launch_scan_bwd2(const BwdArgs& a, int dtype, int T, bool glds, hipStream_t stream);
 hipError_t launch_scan_bwd3(const BwdArgs& a, int dtype, bool glds, hipStream_t stream);   // a.f.R = waves per workgroup
+hipError_t launch_scan_fwd4(const FwdArgs& a, hipStream_t stream);   // a.R = waves (4 rows each), a.rowblocks = workgroups per (batch, group)
 hipError_t launch_scan_bwd4(const BwdArgs& a, hipStream_t stream);   // a.f.R = waves (4 rows each), a.slab2 = states per barrier
 hipError_t launch_reduce_partials(const BwdArgs& a, hipStream_t stream);
 hipError_t bwd4_prof_read(unsigned long long* out16);

@@ -299,7 +299,9 @@ def test_checkpoint_tensor_shape_and_documented_layout():
     out3, xq = _core().fwd_ext(*args, True, ckpt_pitch=320)
     assert xq.shape == (batch, KD, 16 * N) and torch.equal(out3, out)
     out4, xo = _core().fwd_ext(*args, True, ckpt_pitch=160)
-    assert xo.shape == (batch, KD, 32 * N) and torch.equal(out4, out)
+    assert xo.shape == (batch, KD, 32 * N)
+    # pitch 160 runs the quad-row forward (csrc/scan_fwd4.hip): other summation order, same values to rounding
+    torch.testing.assert_close(out4, out, rtol=2e-5, atol=2e-6 * float(out.abs().max()))
     xf, xq, xo = xf.cpu(), xq.cpu(), xo.cpu()
     for pitch, xt in ((1280, x), (640, xf), (320, xq), (160, xo)):
         for j in range((L + pitch - 1) // pitch):

@@ -8,15 +8,15 @@ mkdir -p $OUT
 cd $R
 export TMPDIR=/tmp
 ( time timeout 300 python -c "import __graft_entry__ as g; g.smoke()" ) > $OUT/smoke.log 2>&1; tail -2 $OUT/smoke.log
-( time timeout 900 python -m pytest tests -m gpu -x -q ) > $OUT/pytest_gpu.log 2>&1; tail -3 $OUT/pytest_gpu.log
+( time timeout 1500 python -m pytest tests -m gpu -x -q ) > $OUT/pytest_gpu.log 2>&1; tail -3 $OUT/pytest_gpu.log
 timeout 300 python tools/scan_bench.py --iters 10 --fine --out $OUT/scan_bench.jsonl > $OUT/scan_bench.log 2>&1
 ( time timeout 600 python bench.py --kernel-report $OUT/kernels.json ) > $OUT/bench.log 2>&1; grep "^{" $OUT/bench.log | cut -c1-900
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_scan -o scan -- python $R/tools/scan_bench.py --shapes enc_s0,enc_s2_b16,enc_s0_b8,dec_s0_b8,conmb_s0_b8 --iters 5 --fine > $OUT/rocprof_scan.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_bench -o bench -- python $R/bench.py --steps 2 --warmup 2 --no-cpu-baseline > $OUT/rocprof_bench.log 2>&1
 cd $R
-python tools/prof_summary.py $OUT/prof_bench/bench_kernel_trace.csv --last-ms 700 --top 60 > $OUT/bench_last700ms_kernel_stats.txt 2>&1
+python tools/prof_summary.py $OUT/prof_bench/bench_kernel_trace.csv --last-ms 460 --top 60 > $OUT/bench_last460ms_kernel_stats.txt 2>&1
 python tools/prof_summary.py $OUT/prof_scan/scan_kernel_stats.csv --top 12 > $OUT/scan_bench_kernel_stats.txt 2>&1
 rm -f $OUT/prof_bench/bench_kernel_trace.csv $OUT/prof_scan/scan_kernel_trace.csv
 bash tools/gpu_pmc.sh $TAG/pmc enc_s2_b16 all > $OUT/pmc.log 2>&1; tail -6 $OUT/pmc.log
-head -14 $OUT/bench_last700ms_kernel_stats.txt | cut -c1-160
+head -14 $OUT/bench_last460ms_kernel_stats.txt | cut -c1-160
