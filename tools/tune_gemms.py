@@ -25,6 +25,9 @@ def main():
     ap.add_argument("--out", required=True)
     ap.add_argument("--batch", default="8")
     ap.add_argument("--backbones", default="sigma_small")
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--classes", type=int, default=40)
     ap.add_argument("--max-ms", type=int, default=20)
     ap.add_argument("--max-iters", type=int, default=20)
     a = ap.parse_args()
@@ -39,7 +42,7 @@ def main():
     from sigma_amd.models.builder import EncoderDecoder
     dev = torch.device("cuda", 0)
     for backbone in a.backbones.split(","):
-        cfg = types.SimpleNamespace(backbone=backbone, decoder="MambaDecoder", num_classes=40, image_height=480, image_width=640,
+        cfg = types.SimpleNamespace(backbone=backbone, decoder="MambaDecoder", num_classes=a.classes, image_height=a.height, image_width=a.width,
                                     pretrained_model=None, bn_eps=1e-3, bn_momentum=0.1)
         cwd = os.getcwd()
         os.chdir("/tmp")
@@ -52,9 +55,9 @@ def main():
         opt = ts.make_optimizer(model)
         for batch in [int(b) for b in a.batch.split(",")]:
             g = torch.Generator(device="cpu").manual_seed(1234)
-            rgb = torch.randn(batch, 3, 480, 640, generator=g).to(dev)
-            mx = torch.randn(batch, 3, 480, 640, generator=g).to(dev)
-            label = torch.randint(0, 40, (batch, 480, 640), generator=g).to(dev)
+            rgb = torch.randn(batch, 3, a.height, a.width, generator=g).to(dev)
+            mx = torch.randn(batch, 3, a.height, a.width, generator=g).to(dev)
+            label = torch.randint(0, a.classes, (batch, a.height, a.width), generator=g).to(dev)
             step = ts.make_step(model, opt, (rgb, mx, label))
             t0 = time.time()
             step()
