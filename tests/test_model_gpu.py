@@ -433,3 +433,23 @@ def test_model_with_split_gemms_meets_the_reference_fixture(monkeypatch):
         if not (abs(d[0] - r[0]) < tol and abs(d[1] - r[1]) < tol and abs(d[2] - r[2]) < tol):
             bad.append((n, d.tolist(), r.tolist()))
     assert not bad, bad[:5]
+
+
+def test_evaluator_flip_pair_as_one_batch_equals_two_passes():
+    """sigma_amd/engine/evaluator_ops.py (engine/evaluator.py:501-522): the flipped pass batched with the plain one."""
+    import types
+    import numpy as np
+    from sigma_amd.engine.evaluator_ops import val_func_process_rgbX
+    model = build_model("sigma_tiny", 9, 96, 128).cuda().eval()
+    rgb, x, _ = fill.make_inputs(1, 96, 128, 9, seed=11)
+    ev = types.SimpleNamespace(val_func=model, is_flip=True)
+    got = val_func_process_rgbX(ev, rgb[0].numpy(), x[0].numpy(), device=0)
+    with torch.no_grad():
+        a = model(rgb.cuda(), x.cuda())[0]
+        b = model(rgb.cuda().flip(-1), x.cuda().flip(-1))[0]
+        ref = torch.exp(a + b.flip(-1))
+    assert got.shape == ref.shape == (9, 96, 128)
+    torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-4 * float(ref.abs().max()))
+    ev.is_flip = False
+    got1 = val_func_process_rgbX(ev, rgb[0].numpy(), x[0].numpy(), device=0)
+    torch.testing.assert_close(got1, torch.exp(a), rtol=1e-4, atol=1e-4 * float(a.exp().abs().max()))
