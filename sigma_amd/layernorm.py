@@ -91,13 +91,21 @@ class LayerNormFn(torch.autograd.Function):
         return dx, dgamma, dbeta, None, dz
 
 
+def _aligned16(*tensors) -> bool:
+    """the kernels issue 16-byte loads / stores on x, gamma, beta: a contiguous view with an odd storage
+    offset, or a parameter inside a flat buffer, must not take the vector path"""
+    return all(t is None or (t.data_ptr() % 16 == 0 and t.is_cuda and t.dtype == torch.float32) for t in tensors)
+
+
 class LayerNorm(nn.LayerNorm):
-    """Drop-in nn.LayerNorm; HIP kernels when the input qualifies."""
+    """Drop-in nn.LayerNorm; HIP kernels when the input qualifies (fp32 GPU tensors, C % 4 == 0, C <= 2048, 16-byte
+    aligned operands), ``F.layer_norm`` otherwise."""
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         C = x.shape[-1] if x.dim() > 0 else 0
         if (x.is_cuda and x.dtype == torch.float32 and self.elementwise_affine and len(self.normalized_shape) == 1
-                and self.weight.dtype == torch.float32 and C % 4 == 0 and 0 < C <= 2048 and x.numel() > 0):
+                and C % 4 == 0 and 0 < C <= 2048 and x.numel() > 0
+                and _aligned16(self.weight, self.bias) and (not x.is_contiguous() or x.data_ptr() % 16 == 0)):
             return LayerNormFn.apply(x, self.weight, self.bias, self.eps)
         return F.layer_norm(x, self.normalized_shape, self.weight, self.bias, self.eps)
 
@@ -107,6 +115,7 @@ class LayerNorm(nn.LayerNorm):
         C = x.shape[-1]
         if (x.is_cuda and x.dtype == torch.float32 and z.dtype == torch.float32 and self.elementwise_affine
                 and len(self.normalized_shape) == 1 and C % 4 == 0 and 0 < C <= 2048 and x.numel() > 0
-                and tuple(z.shape) == tuple(x.shape)):
+                and tuple(z.shape) == tuple(x.shape) and _aligned16(self.weight, self.bias)
+                and (not x.is_contiguous() or x.data_ptr() % 16 == 0)):
             return LayerNormFn.apply(x, self.weight, self.bias, self.eps, z)
         return self.forward(x) * F.silu(z)

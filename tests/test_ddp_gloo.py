@@ -128,3 +128,25 @@ def test_bench_launch_plan_arithmetic():
                 lambda: ts.launch_plan(0, {}, 1, argv, "b", 1)):
         with pytest.raises(SystemExit):
             bad()
+
+
+def test_optimizer_groups_reference_quirk_and_opt_in_fix():
+    """group_weight reproduces the reference's dead isinstance(m, nn.Parameter) branch (raw Parameters are never
+    stepped); include_raw_params=True puts them into the no-decay group."""
+    import torch.nn as nn
+    from sigma_amd import train_step as ts
+
+    class Blk(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lin = nn.Linear(4, 4)
+            self.norm = nn.LayerNorm(4)
+            self.A_logs = nn.Parameter(torch.zeros(4, 2))
+            self.Ds = nn.Parameter(torch.ones(4))
+
+    m = Blk()
+    g = ts.group_weight(m, 1e-3)
+    assert ts.unoptimized_parameters(m, g) == 2
+    g2 = ts.group_weight(m, 1e-3, include_raw_params=True)
+    assert ts.unoptimized_parameters(m, g2) == 0 and len(g2[1]["params"]) == len(g[1]["params"]) + 2
+    assert g2[1]["weight_decay"] == 0.0
