@@ -20,7 +20,7 @@ thread_local std::string g_err;
 
 std::atomic<int> g_opt_fwd_items{0}, g_opt_fwd_waves{0}, g_opt_fwd_tiles{0}, g_opt_fwd_nb{0};
 std::atomic<int> g_opt_bwd_items{0}, g_opt_bwd_waves{0}, g_opt_bwd_nb{0}, g_opt_no_glds{0}, g_opt_bwd_slab2{0}, g_opt_fwd_prefetch{0};
-std::atomic<int> g_opt_bwd_gen{0}, g_opt_bwd_rb{0}, g_opt_bwd_touch{0}, g_opt_bwd_sb{0}, g_opt_bwd_wgs{0}, g_opt_fwd_gen{0};
+std::atomic<int> g_opt_bwd_gen{0}, g_opt_bwd_rb{0}, g_opt_bwd_touch{0}, g_opt_bwd_sb{0}, g_opt_bwd_wgs{0}, g_opt_fwd_gen{0}, g_opt_bwd_seg{0};
 
 int fail(int code, const char* fmt, ...) {
     char buf[512];
@@ -374,6 +374,9 @@ PlanF4 plan_fwd4(const sigma_scan_fwd_params* p, bool vec) {
     if (!glds_ok(p, vec)) return pl;
     const int rpg = p->dim / p->n_groups;
     if (rpg % 4 != 0) return pl;
+    // a wave keeps its four rows for the whole sequence: with few rows (the launches whose backward splits the sequence
+    // instead) the 64-lane kernel with its in-workgroup sequence split is faster ((2,768,19200): 297 vs 715 us)
+    if ((long)p->batch * p->dim < 8192 && g_opt_fwd_gen.load() != 2) return pl;
     const int quads = rpg / 4;
     const int fr = g_opt_fwd_waves.load();
     const long bg = (long)p->batch * p->n_groups;
@@ -393,7 +396,7 @@ PlanF4 plan_fwd4(const sigma_scan_fwd_params* p, bool vec) {
 
 // scan_bwd4 (scan_bwd4.hip): quad-row mapping, 160-position tiles; a workgroup is W waves x 4 rows and walks RB
 // row blocks per tile; P = rows_per_group / (4 * W * RB) workgroups share a group; SB states share a barrier.
-struct Plan4 { bool ok; int W, RB, SB, P, grid, nbuf, wgs; size_t lds; };
+struct Plan4 { bool ok; int W, RB, SB, P, grid, nbuf, wgs, S, seg_tiles; size_t lds; };
 
 Plan4 plan_bwd4(const sigma_scan_fwd_params* p, bool vec) {
     Plan4 pl;
@@ -416,24 +419,40 @@ Plan4 plan_bwd4(const sigma_scan_fwd_params* p, bool vec) {
     const int wgs = g_opt_bwd_wgs.load() == 2 ? 2 : 1;
     const long slots = (long)kCUs * wgs;
     const long bg = (long)p->batch * p->n_groups;
-    int W = 0, RB = 1;
+    // Sequence segments ("bwd_seg": 0 = automatic, 1 = never, k = k segments): with few rows the workgroups cannot
+    // fill the chip, so the sequence is cut into S segments run by different workgroups; a pre-pass
+    // (rev_summary4_kernel, ~25 % of the work) provides the reverse carry entering each segment.
+    const int ntiles = (p->seqlen + 159) / 160;
+    int fseg = g_opt_bwd_seg.load();
+    auto seg_legal = [&](int s) {
+        return s == 1 || ((ntiles + s - 1) / s >= 2 && ((ntiles + s - 1) / s) * (s - 1) < ntiles);   // >= 2 tiles each, none empty
+    };
+    if (fseg > 1 && !seg_legal(fseg)) fseg = 1;                              // a forced count that cannot be served
+    static const int seg_cand[] = {1, 2, 3, 4, 6, 8, 12, 16};
+    int W = 0, RB = 1, S = 1;
     double best = 1e300;
-    for (int w = wgs == 2 ? 8 : 16; w >= 1; --w) {
-        if (quads % w != 0) continue;
-        if (fr > 0 && fr <= 16 && quads % fr == 0 && w != fr) continue;          // forced waves (when legal)
-        const int rowblocks_w = quads / w;
-        for (int d = rowblocks_w; d >= 1; --d) {
-            if (rowblocks_w % d != 0) continue;
-            if (frb > 0) {                                                       // forced row blocks: largest divisor <= frb
-                int want = frb;
-                while (want > 1 && rowblocks_w % want != 0) --want;
-                if (d != want) continue;
+    for (int si = 0; si < 8; ++si) {
+        const int s = seg_cand[si];
+        if (fseg == 1 && s != 1) continue;
+        if (fseg > 1 && s != fseg) continue;
+        if (!seg_legal(s)) continue;
+        for (int w = wgs == 2 ? 8 : 16; w >= 1; --w) {
+            if (quads % w != 0) continue;
+            if (fr > 0 && fr <= 16 && quads % fr == 0 && w != fr) continue;      // forced waves (when legal)
+            const int rowblocks_w = quads / w;
+            for (int d = rowblocks_w; d >= 1; --d) {
+                if (rowblocks_w % d != 0) continue;
+                if (frb > 0) {                                                   // forced row blocks: largest divisor <= frb
+                    int want = frb;
+                    while (want > 1 && rowblocks_w % want != 0) --want;
+                    if (d != want) continue;
+                }
+                if ((size_t)d * 4 * w * N * sizeof(float) > (wgs == 2 ? 8u : 24u) * 1024) continue;   // reverse carries of the chunk's rows
+                const long grid = bg * (rowblocks_w / d) * s;
+                const double rounds = (double)((grid + slots - 1) / slots);
+                const double cost = rounds * d * w * (0.73 + 4.3 / w) / s * (s > 1 ? 1.25 : 1.0);
+                if (cost < best * 0.999) { best = cost; W = w; RB = d; S = s; }
             }
-            if ((size_t)d * 4 * w * N * sizeof(float) > (wgs == 2 ? 8u : 24u) * 1024) continue;   // reverse carries of the chunk's rows
-            const long grid = bg * (rowblocks_w / d);
-            const double rounds = (double)((grid + slots - 1) / slots);
-            const double cost = rounds * d * w * (0.73 + 4.3 / w);
-            if (cost < best * 0.999) { best = cost; W = w; RB = d; }
         }
     }
     if (W == 0) return pl;
@@ -450,9 +469,10 @@ Plan4 plan_bwd4(const sigma_scan_fwd_params* p, bool vec) {
         else return pl;
     }
     pl.nbuf = nbuf; pl.wgs = wgs;
+    pl.S = S; pl.seg_tiles = (ntiles + S - 1) / S;
     pl.ok = true;
     pl.W = W; pl.RB = RB; pl.SB = SB; pl.P = rowblocks / RB;
-    pl.grid = p->batch * p->n_groups * pl.P;
+    pl.grid = p->batch * p->n_groups * pl.P * S;
     pl.lds = sigma::bwd4_lds_bytes(W, N, SB, RB, nbuf);
     return pl;
 }
@@ -479,7 +499,8 @@ OptDesc g_opts[] = {
     {"bwd_slab2", &g_opt_bwd_slab2, {0, 1, 2, -1}},        // 1 = two dB/dC slab sets when they fit
     {"fwd_prefetch", &g_opt_fwd_prefetch, {0, 1, 2, -1}},  // 2 = no register prefetch of the next tile's u/delta (T = 10)
     {"bwd_gen", &g_opt_bwd_gen, {0, 1, 2, 3, -1}},         // backward kernel: 1 = scan_bwd.hip, 2 = scan_bwd2.hip, 3 / 0 = best legal
-    {"fwd_gen", &g_opt_fwd_gen, {0, 1, -1}},                 // 1 = never the quad-row forward (scan_fwd4.hip)
+    {"bwd_seg", &g_opt_bwd_seg, {0, 1, 2, 3, 4, 6, 8, 12}},     // quad-row backward: sequence segments (0 auto, 1 never)
+    {"fwd_gen", &g_opt_fwd_gen, {0, 1, 2, -1}},              // 1 = never the quad-row forward (scan_fwd4.hip), 2 = also with few rows
     {"bwd_wgs", &g_opt_bwd_wgs, {0, 1, 2, -1}},              // quad-row backward: 2 = two small workgroups per CU
     {"bwd_sb", &g_opt_bwd_sb, {0, 1, 2, 4, 8, -1}},          // quad-row backward: states per barrier (0 = 2)
     {"bwd_touch", &g_opt_bwd_touch, {0, 1, 2, -1}},   // L2 warm-up touches of the next row step: 1 = on, 2 = off, 0 = on in scan_bwd4 only
@@ -531,7 +552,8 @@ int sigma_scan_bwd_plan(const sigma_scan_bwd_params* p, int32_t plan[6]) {
         const Plan4 p4 = plan_bwd4(&p->fwd, true);
         if (!p4.ok) return fail(SIGMA_ERR_BAD_SHAPE, "ckpt_pitch 160 (quad-row backward) is not available for this problem");
         // items = 10, rows slot = waves (4 rows each), states_per_block slot = -(100 + states per barrier)
-        plan[0] = 10; plan[1] = p4.W; plan[2] = p4.grid; plan[3] = (int32_t)p4.lds; plan[4] = -p4.RB; plan[5] = -(100 + p4.SB);
+        // items slot: 10 (+ 1000 x sequence segments when the sequence is split)
+        plan[0] = 10 + (p4.S > 1 ? 1000 * p4.S : 0); plan[1] = p4.W; plan[2] = p4.grid; plan[3] = (int32_t)p4.lds; plan[4] = -p4.RB; plan[5] = -(100 + p4.SB);
         return SIGMA_OK;
     }
     const Plan3 p3 = plan_bwd3(&p->fwd, true);
@@ -590,7 +612,9 @@ int64_t sigma_scan_bwd_workspace_bytes(const sigma_scan_bwd_params* q) {
     if (p->ckpt_pitch == SIGMA_SCAN_CKPT_PITCH_160) {
         const Plan4 p4 = plan_bwd4(p, true);
         if (!p4.ok) { fail(SIGMA_ERR_BAD_SHAPE, "ckpt_pitch 160 (quad-row backward) is not available for this problem"); return -1; }
-        return p4.P <= 1 ? 0 : (int64_t)2 * p4.P * p->batch * p->n_groups * (int64_t)p->dstate * p->seqlen * (int64_t)sizeof(float);
+        const int64_t slabs = p4.P <= 1 ? 0 : (int64_t)2 * p4.P * p->batch * p->n_groups * (int64_t)p->dstate * p->seqlen * (int64_t)sizeof(float);
+        const int64_t summ = p4.S <= 1 ? 0 : (int64_t)(p4.S - 1) * p->batch * p->dim * (int64_t)p->dstate * 2 * (int64_t)sizeof(float);
+        return slabs + summ;
     }
     const Plan3 p3 = plan_bwd3(p, true);     // no plan's workgroup count depends on alignment
     if (p3.ok)
@@ -638,11 +662,13 @@ int sigma_selective_scan_bwd(const sigma_scan_bwd_params* q, void* stream) {
         return fail(SIGMA_ERR_BAD_OPTION, "ckpt_pitch 320 needs the second-generation backward (option bwd_gen != 1)");
     if (pl.lds > kLdsLimit) return fail(SIGMA_ERR_BAD_SHAPE, "LDS budget exceeded (%zu B)", pl.lds);
     const int P = p4.ok ? p4.P : p3.ok ? p3.P : (p2.ok ? p2.P : (p->dim / p->n_groups) / pl.rows);
-    const int64_t slab = (int64_t)P * p->batch * p->n_groups * (int64_t)p->dstate * p->seqlen;
-    if (P > 1) {
-        if (!q->workspace || q->workspace_bytes < 2 * slab * (int64_t)sizeof(float))
-            return fail(SIGMA_ERR_NULL_ARG, "workspace of %lld bytes required (got %lld)",
-                        (long long)(2 * slab * (int64_t)sizeof(float)), (long long)q->workspace_bytes);
+    const int64_t slab = P > 1 ? (int64_t)P * p->batch * p->n_groups * (int64_t)p->dstate * p->seqlen : 0;
+    const int S = p4.ok ? p4.S : 1;
+    const int64_t summ_floats = S > 1 ? (int64_t)(S - 1) * p->batch * p->dim * (int64_t)p->dstate * 2 : 0;
+    if (P > 1 || S > 1) {
+        const int64_t need = (2 * slab + summ_floats) * (int64_t)sizeof(float);
+        if (!q->workspace || q->workspace_bytes < need)
+            return fail(SIGMA_ERR_NULL_ARG, "workspace of %lld bytes required (got %lld)", (long long)need, (long long)q->workspace_bytes);
         if (!aligned_to(q->workspace, 16)) return fail(SIGMA_ERR_BAD_STRIDE, "workspace must be 16-byte aligned");
     }
     sigma::BwdArgs a;
@@ -671,7 +697,12 @@ int sigma_selective_scan_bwd(const sigma_scan_bwd_params* q, void* stream) {
         a.flags = (t == 1 || (t == 0 && p4.ok)) ? 0 : 1;
     }
     a.RB = p4.ok ? p4.RB : p3.ok ? p3.RB : (p2.ok ? p2.RB : 1);
-    if (p4.ok) { a.slab2 = p4.SB; a.f.NB = p4.nbuf; if (p4.wgs == 2) a.flags |= 2; }
+    a.S = 1;
+    if (p4.ok) {
+        a.slab2 = p4.SB; a.f.NB = p4.nbuf; if (p4.wgs == 2) a.flags |= 2;
+        a.S = p4.S; a.seg_tiles = p4.seg_tiles;
+        a.summ = S > 1 ? static_cast<float*>(q->workspace) + 2 * slab : nullptr;
+    }
     hipError_t e = p4.ok ? sigma::launch_scan_bwd4(a, static_cast<hipStream_t>(stream)) : p3.ok ? sigma::launch_scan_bwd3(a, p->io_dtype, pl.glds, static_cast<hipStream_t>(stream)) : p2.ok ? sigma::launch_scan_bwd2(a, p->io_dtype, pl.items, pl.glds, static_cast<hipStream_t>(stream))
                          : sigma::launch_scan_bwd(a, p->io_dtype, pl.items, pl.glds, static_cast<hipStream_t>(stream));
     if (e != hipSuccess) return fail(SIGMA_ERR_LAUNCH, "scan_bwd launch failed: %s", hipGetErrorString(e));

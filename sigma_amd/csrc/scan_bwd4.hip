@@ -89,7 +89,7 @@ __device__ __forceinline__ float colsum1(const float* __restrict__ colp, int str
 }  // namespace
 
 template <bool REV>
-__device__ __forceinline__ void scan_bwd4_body(const BwdArgs& q, float* smem, int b, int g, int chunk) {
+__device__ __forceinline__ void scan_bwd4_body(const BwdArgs& q, float* smem, int b, int g, int chunk, int seg) {
     constexpr int T = kT4;
     const FwdArgs& p = q.f;
     const int W = blockDim.x >> 6;                    // waves; 4 rows each
@@ -128,12 +128,28 @@ __device__ __forceinline__ void scan_bwd4_body(const BwdArgs& q, float* smem, in
         oB = q.ws_dB + slab; oC = q.ws_dC + slab; o_nsB = L; o_nsC = L;
     }
 
-    for (int i = tid; i < RB * 4 * W * N; i += blockDim.x) sRv[i] = 0.0f;
+    // Sequence segments (few rows, long sequences): this workgroup owns tiles [t_lo, t_hi).  The reverse carry entering
+    // its right end is the composition of the summaries (decay product P, value E with zero carry) of the segments to
+    // its right, written by rev_summary4_kernel: carry <- E_t + P_t * carry for t = S-1 .. seg+1.
+    const int ntiles_all = (L + kTile4 - 1) / kTile4;
+    const int t_lo = q.S > 1 ? seg * q.seg_tiles : 0;
+    const int t_hi = q.S > 1 ? (t_lo + q.seg_tiles < ntiles_all ? t_lo + q.seg_tiles : ntiles_all) : ntiles_all;
+    for (int i = tid; i < RB * 4 * W * N; i += blockDim.x) {
+        float carry = 0.0f;
+        if (q.S > 1) {
+            const int rl = i / N, n = i - rl * N;
+            const long rn = ((long)b * p.dim + (row_c0 + rl)) * N + n;
+            for (int t = q.S - 1; t > seg; --t) {
+                const float2 pe = reinterpret_cast<const float2*>(q.summ)[(long)(t - 1) * p.batch * p.dim * N + rn];
+                carry = fmaf(pe.x, carry, pe.y);
+            }
+        }
+        sRv[i] = carry;
+    }
     // never multiply uninitialised LDS bits (stale/NaN) into the padding of the last tile
     for (int i = tid; i < nbuf * bufsz / 4; i += blockDim.x) reinterpret_cast<float4*>(sBC)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
 
-    const int ntiles = (L + kTile4 - 1) / kTile4;
     auto stage = [&](int buf, int tile) {
         stage_tile4<REV>(sBC + buf * bufsz, Bg, Cg, (int)p.B_ns, (int)p.C_ns, N, tile, L);
     };
@@ -167,16 +183,16 @@ __device__ __forceinline__ void scan_bwd4_body(const BwdArgs& q, float* smem, in
     int buf = 0;
     int grp = 0;                                       // state groups processed (slab set parity)
     PROF_DECL
-    stage(0, ntiles - 1);
+    stage(0, t_hi - 1);
     lds_dma_wait();
     __syncthreads();
     PROF(0)
 
-    for (int j = ntiles - 1; j >= 0; --j) {
+    for (int j = t_hi - 1; j >= t_lo; --j) {
         const int l0 = j * kTile4;
         const int lbase_t = l0 + li * T;
         const float* cur = sBC + buf * bufsz;
-        if (nbuf == 2 && j > 0) stage(buf ^ 1, j - 1); // lands while this tile is processed
+        if (nbuf == 2 && j > t_lo) stage(buf ^ 1, j - 1); // lands while this tile is processed
         for (int rb = 0; rb < RB; ++rb) {
             // laundered per row step: the ten load offsets derived from lbase are row-step invariant, and hoisted out
             // of this loop they lived in scratch in the 128-VGPR build (30 reloads of 512 B per wave and row step)
@@ -241,7 +257,7 @@ __device__ __forceinline__ void scan_bwd4_body(const BwdArgs& q, float* smem, in
                 if (n == N - 3 && !(q.flags & 1)) {
                     // next step of THIS wave: same tile, next row block -- or the tile to the left of its first rows
                     const int jn = (rb + 1 < RB) ? j : j - 1;
-                    if (jn >= 0) {
+                    if (jn >= t_lo) {
                         cold4_t kt = cold_args4();
                         const int trow = lane / 6, tline = lane - trow * 6;          // 24 lanes: 4 rows x 6 lines
                         const int rn = row_c0 + (((rb + 1 < RB) ? rb + 1 : 0) * W + wave) * 4 + trow;
@@ -330,7 +346,7 @@ __device__ __forceinline__ void scan_bwd4_body(const BwdArgs& q, float* smem, in
                     // slabs of this state group complete; at the end of the tile also "next B/C image landed"
                     if (n == N - 1 && rb == RB - 1) {
                         if (nbuf == 2) { lds_dma_wait(); __syncthreads(); }
-                        else { lds_barrier(); if (j > 0) stage(0, j - 1); }      // every wave is done with this tile's image
+                        else { lds_barrier(); if (j > t_lo) stage(0, j - 1); }   // every wave is done with this tile's image
                     } else {
                         lds_barrier();
                     }
@@ -438,7 +454,7 @@ __device__ __forceinline__ void scan_bwd4_body(const BwdArgs& q, float* smem, in
             PROF(8)                                            // row epilogue
         }
         if (nbuf == 2) buf ^= 1;
-        else if (j > 0) { lds_dma_wait(); __syncthreads(); }
+        else if (j > t_lo) { lds_dma_wait(); __syncthreads(); }
     }
     PROF_FLUSH
 }
@@ -448,20 +464,141 @@ __global__ void __launch_bounds__(64 * MAXW)
 scan_bwd4_kernel(const BwdArgs q) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int lb = xcd_logical_block(blockIdx.x, gridDim.x);
-    const int per_b = q.f.G * q.P;                    // workgroups per batch entry
+    const int PS = q.P * q.S;                         // workgroups per (batch, group): row chunks x sequence segments
+    const int per_b = q.f.G * PS;
     const int b = lb / per_b;
     const int rem = lb - b * per_b;
-    const int g = rem / q.P;
-    const int chunk = rem - g * q.P;
-    if ((q.f.rev_mask >> g) & 1u) scan_bwd4_body<true>(q, smem, b, g, chunk);
-    else scan_bwd4_body<false>(q, smem, b, g, chunk);
+    const int g = rem / PS;
+    const int rem2 = rem - g * PS;
+    const int chunk = rem2 / q.S;
+    const int seg = rem2 - chunk * q.S;
+    if ((q.f.rev_mask >> g) & 1u) scan_bwd4_body<true>(q, smem, b, g, chunk, seg);
+    else scan_bwd4_body<false>(q, smem, b, g, chunk, seg);
+}
+
+// ---- reverse summaries of the sequence segments (S > 1) ----------------------------------------------------------
+// For segment s = 1 .. S-1, row r and state n: (P, E) with  e(left end of s) = E + P * e(right end of s), i.e. the
+// decay product of the segment and the reverse recurrence e_k = a_k (dout_k C_k + e_{k+1}) run over it with zero
+// carry.  Same lane mapping as the main kernel; per tile the in-lane fold + 4-step row scan give the tile's E at lane
+// 0 of the row, the tile's P is exp2(A2 * sum of delta over the tile); tiles compose right to left in two lane vectors.
+template <bool REV>
+__device__ __forceinline__ void rev_summary4_body(const BwdArgs& q, float* smem, int b, int g, int chunk, int seg) {
+    constexpr int T = kT4;
+    const FwdArgs& p = q.f;
+    const int W = blockDim.x >> 6;
+    const int N = p.N, L = p.L;
+    const int bufsz = 2 * N * kTile4;
+    float* sBC = smem;                                // [2][2][N][160] (only the C half is read)
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int li = lane & 15;
+    const int qr = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool vec = p.vec_ok != 0;
+    const bool li0 = li == 0;
+    const int rowbase4 = (lane & 48) << 2;
+    const int vshift = 16 - N;
+
+    const int r = g * p.rows_per_group + (chunk * W + wave) * 4 + qr;
+    const int gr = r - ((g - (g >> q.g_gshift)) * p.rows_per_group);
+    const float* __restrict__ d_row = reinterpret_cast<const float*>(p.delta) + (long)b * p.dt_bs + (long)r * p.dt_ds;
+    const float* __restrict__ g_row = reinterpret_cast<const float*>(q.dout) + (long)b * q.g_bs + (long)gr * q.g_ds;
+    const float* __restrict__ Bg = reinterpret_cast<const float*>(p.B) + (long)b * p.B_bs + (long)g * p.B_gs;
+    const float* __restrict__ Cg = reinterpret_cast<const float*>(p.C) + (long)b * p.C_bs + (long)g * p.C_gs;
+    const int pr = param_row(r, g, p.rows_per_group, p.pswap);
+    const float bias = p.bias ? p.bias[pr] : 0.0f;
+    float A2v = 0.0f;
+    if (li < N) A2v = p.A[(long)pr * p.A_ds + (long)li * p.A_ns] * kLog2e;
+    float PV = 1.0f, EV = 0.0f;                       // state n in lane vshift + n
+
+    const int ntiles_all = (L + kTile4 - 1) / kTile4;
+    const int t_lo = seg * q.seg_tiles;
+    const int t_hi = t_lo + q.seg_tiles < ntiles_all ? t_lo + q.seg_tiles : ntiles_all;
+    for (int i = tid; i < 2 * bufsz / 4; i += blockDim.x) reinterpret_cast<float4*>(sBC)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    auto stage = [&](int buf, int tile) {
+        stage_tile4<REV>(sBC + buf * bufsz, Bg, Cg, (int)p.B_ns, (int)p.C_ns, N, tile, L);
+    };
+    stage(0, t_hi - 1);
+    lds_dma_wait();
+    __syncthreads();
+    int buf = 0;
+    for (int j = t_hi - 1; j >= t_lo; --j) {
+        const float* cur = sBC + buf * bufsz;
+        if (j > t_lo) stage(buf ^ 1, j - 1);
+        const int lbase = j * kTile4 + li * T;
+        float dl[T], gg[T];
+        float dsum = 0.0f;
+        {
+            float dv[T];
+            load_items<float, T, REV>(d_row, lbase, L, vec, dv);
+            load_items<float, T, REV>(g_row, lbase, L, vec, gg);
+#pragma unroll
+            for (int k = 0; k < T; ++k) {
+                float d = dv[k] + bias;
+                if (p.softplus) { float sg; d = softplus_ref(d, sg); }
+                d = (lbase + k < L) ? d : 0.0f;
+                dl[k] = d;
+                dsum += d;
+            }
+        }
+        const float dsum_row = row_pick(row_sum_to_lane0(dsum), rowbase4);      // sum of delta over the row's tile
+        float PVn = 0.0f, EVn = 0.0f;
+#pragma unroll 1
+        for (int n = 0; n < N; ++n) {
+            const float A2 = row_pick(A2v, rowbase4 + 4 * n);
+            const float Pold = row_pick(PV, rowbase4 + 4 * (vshift + n));
+            const float Eold = row_pick(EV, rowbase4 + 4 * (vshift + n));
+            const float* tC = cur + (N + n) * kTile4;
+            float e = 0.0f;
+#pragma unroll
+            for (int qq = T / 2 - 1; qq >= 0; --qq) {
+                float cq[2];
+                lds_read_pair<REV>(tC, li, qq, cq);
+#pragma unroll
+                for (int jj = 1; jj >= 0; --jj) {
+                    const int k = 2 * qq + jj;
+                    e = fast_exp2(dl[k] * A2) * fmaf(gg[k], cq[jj], e);
+                }
+            }
+            float prv = fast_exp2(A2 * dsum);
+            row_mscan_inclusive_rev(prv, e);                                     // lane 0: the tile's E
+            const float Ptile = fast_exp2(A2 * dsum_row);
+            const float En = fmaf(Ptile, Eold, e);
+            const float Pn = Ptile * Pold;
+            EVn = row_rotate_left(li0 ? En : EVn);
+            PVn = row_rotate_left(li0 ? Pn : PVn);
+        }
+        PV = PVn; EV = EVn;
+        lds_dma_wait();
+        __syncthreads();
+        buf ^= 1;
+    }
+    if (li >= vshift)
+        reinterpret_cast<float2*>(q.summ)[((long)(seg - 1) * p.batch * p.dim + (long)b * p.dim + r) * N + (li - vshift)] = make_float2(PV, EV);
+}
+
+__global__ void __launch_bounds__(512)
+rev_summary4_kernel(const BwdArgs q, int Pq) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lb = blockIdx.x;
+    const int PS = Pq * (q.S - 1);                    // row chunks x segments 1..S-1
+    const int per_b = q.f.G * PS;
+    const int b = lb / per_b;
+    const int rem = lb - b * per_b;
+    const int g = rem / PS;
+    const int rem2 = rem - g * PS;
+    const int chunk = rem2 / (q.S - 1);
+    const int seg = 1 + rem2 - chunk * (q.S - 1);
+    if ((q.f.rev_mask >> g) & 1u) rev_summary4_body<true>(q, smem, b, g, chunk, seg);
+    else rev_summary4_body<false>(q, smem, b, g, chunk, seg);
 }
 
 // a.f.R = waves per workgroup (4 rows each), a.slab2 = states per barrier, a.RB = row blocks per workgroup
 template <int MAXW>
 static hipError_t launch_bwd4_t(const BwdArgs& a, hipStream_t stream) {
     const size_t lds = bwd4_lds_bytes(a.f.R, a.f.N, a.slab2, a.RB, a.f.NB);
-    const int grid = a.f.batch * a.f.G * a.P;
+    const int grid = a.f.batch * a.f.G * a.P * a.S;
     auto kern = scan_bwd4_kernel<MAXW>;
     static std::atomic<size_t> lds_cap[kMaxDevices];
     int dev = 0;
@@ -479,7 +616,34 @@ static hipError_t launch_bwd4_t(const BwdArgs& a, hipStream_t stream) {
     return launch_reduce_partials(a, stream);
 }
 
+// the pre-pass of the sequence split: W4 = waves per workgroup (<= 8) over the same rows, one workgroup per segment 1..S-1
+static hipError_t launch_rev_summary4(const BwdArgs& a, hipStream_t stream) {
+    const int quads = a.f.rows_per_group / 4;
+    int W4 = 8;
+    while (W4 > 1 && quads % W4 != 0) --W4;
+    const int Pq = quads / W4;
+    const size_t lds = fwd4_lds_bytes(a.f.N);
+    const int grid = a.f.batch * a.f.G * Pq * (a.S - 1);
+    auto kern = rev_summary4_kernel;
+    static std::atomic<size_t> lds_cap[kMaxDevices];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= kMaxDevices) dev = 0;
+    if (lds > 48 * 1024 && lds > lds_cap[dev].load(std::memory_order_relaxed)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        lds_cap[dev].store(lds, std::memory_order_relaxed);
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(W4 * 64), lds, stream, a, Pq);
+    return hipGetLastError();
+}
+
 hipError_t launch_scan_bwd4(const BwdArgs& a, hipStream_t stream) {
+    if (a.S > 1) {
+        hipError_t e = launch_rev_summary4(a, stream);
+        if (e != hipSuccess) return e;
+    }
     // up to 12 waves: ~150 VGPRs, 3 waves per SIMD; 13..16 waves -- or two workgroups per CU (flags bit 1): the
     // 128-VGPR build
     return (a.f.R > 12 || (a.flags & 2)) ? launch_bwd4_t<16>(a, stream) : launch_bwd4_t<12>(a, stream);

@@ -512,6 +512,9 @@ struct BwdArgs {
     int slab2;                      // two dB/dC slab sets (by state parity): one barrier per state instead of two
     int flags;                      // bit 0: no L2 warm-up touches (scan_bwd2; cleared by option "bwd_touch")
     int RB;                         // scan_bwd2: row blocks (of R rows) a workgroup walks per tile; P = rows_per_group / (R * RB)
+    int S;                          // scan_bwd4: sequence segments (1 = whole sequence per workgroup)
+    int seg_tiles;                  // scan_bwd4: 160-tiles per segment
+    float* summ;                    // scan_bwd4, S > 1: [(S-1)][batch][dim][N][2] reverse summaries (decay product, e) of segments 1..S-1
     long g_bs, g_ds, du_bs, du_ds, dd_bs, dd_ds, dA_ds, dA_ns;
     long dB_bs, dB_gs, dB_ns, dC_bs, dC_gs, dC_ns;
 };

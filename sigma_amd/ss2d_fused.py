@@ -56,6 +56,8 @@ def ckpt_pitch_for(seqlen: int, dstate: int = 16, rows: int = 0, quad_ok: bool =
         operands) whenever there are enough rows for workgroups of 8+ waves on every CU (batch * dim >= 8192 with
         8+ states; >= 12288 with 4 states up to 4800 elements, where the per-tile overhead weighs more) -- 8-27 %
         faster than the tiles below on the encoder launches (profiles/r02_bwd4_shapes.txt, r02_bwd4_mid.txt);
+      * 160 as well for 8+ states, few rows and L >= 4800, where the quad-row backward splits the sequence into
+        segments (csrc/scan_bwd4.hip, rev_summary4_kernel);
       * 320-element tiles for short sequences (L = 300 pads to 320 instead of 640), for 4-state scans up to 1280
         elements (state-parallel backward, csrc/scan_bwd3.hip) and for 16-state scans up to 4800 elements with
         enough rows for the row-block loop of csrc/scan_bwd2.hip;
@@ -65,6 +67,11 @@ def ckpt_pitch_for(seqlen: int, dstate: int = 16, rows: int = 0, quad_ok: bool =
         if forced != 160 or quad_ok:
             return forced
     if quad_ok and ((dstate >= 8 and rows >= 8192) or (rows >= 12288 and seqlen <= 4800)):
+        return 160
+    if quad_ok and dstate >= 8 and seqlen >= 4800:
+        # few rows, long sequences (one image per GPU, sigma_base 720x1280): the quad-row backward cuts the sequence
+        # into segments run by different workgroups (profiles/r02_bwd4_segments.txt: (1,768,19200) 1081 -> 504 us,
+        # (2,1024,57600) 4249 -> 2209 us); the forward stays on the 64-lane kernel, which writes the 160-pitch checkpoints
         return 160
     if seqlen <= 320 or (dstate <= 4 and seqlen <= 1280):
         return 320

@@ -57,12 +57,16 @@ def test_every_model_shape_gets_a_legal_plan(pitch):
         assert ws >= 0
         if t5 <= -100:                         # quad-row backward: W waves x 4 rows x RB row blocks per workgroup
             W, RB, SB = rows, -t4, -t5 - 100
-            assert pitch == 160 and items == 10 and SB in (1, 2, 4, 8) and N % SB == 0
+            S = items // 1000 if items >= 1000 else 1              # sequence segments
+            assert pitch == 160 and items % 1000 == 10 and SB in (1, 2, 4, 8) and N % SB == 0
             quads = rpg // 4
             assert quads % W == 0 and (quads // W) % RB == 0
             P = quads // W // RB
-            assert grid == batch * G * P
-            assert ws == (0 if P == 1 else 2 * P * batch * G * N * L * 4)
+            assert grid == batch * G * P * S
+            ntiles = (L + 159) // 160
+            seg_tiles = (ntiles + S - 1) // S
+            assert S == 1 or (seg_tiles >= 2 and seg_tiles * (S - 1) < ntiles)
+            assert ws == (0 if P == 1 else 2 * P * batch * G * N * L * 4) + (S - 1) * batch * dim * N * 8
         elif t4 < 0:                           # second generation / state-parallel: -t4 row blocks per workgroup
             assert pitch in (640, 320)
         seen += 1

@@ -431,15 +431,18 @@ def test_every_launch_geometry_is_correct(opt):
 
 
 QUAD_OPTS = [{}, {"bwd_sb": 1}, {"bwd_sb": 4}, {"bwd_waves": 3}, {"bwd_waves": 6, "bwd_rb": 2}, {"bwd_waves": 12}, {"bwd_waves": 16},
-             {"bwd_rb": 1}, {"bwd_touch": 2}, {"bwd_waves": 16, "bwd_sb": 1, "bwd_touch": 1}]
+             {"bwd_rb": 1}, {"bwd_touch": 2}, {"bwd_waves": 16, "bwd_sb": 1, "bwd_touch": 1}, {"bwd_wgs": 2},
+             {"bwd_seg": 2}, {"bwd_seg": 4, "bwd_waves": 3}, {"bwd_seg": 3, "bwd_rb": 1, "bwd_nb": 1}, {"bwd_seg": 1}]
 
 
 @pytest.mark.parametrize("opts", QUAD_OPTS, ids=[",".join(f"{k}={v}" for k, v in o.items()) or "auto" for o in QUAD_OPTS])
-@pytest.mark.parametrize("shape", [(2, 768, 1200, 16, 4, 0b1010, 1), (2, 384, 2564, 4, 2, 0b10, 1), (3, 192, 300, 8, 1, 0, 0)],
-                         ids=["2x768x1200xN16", "2x384x2564xN4", "3x192x300xN8"])
+@pytest.mark.parametrize("shape", [(2, 768, 1200, 16, 4, 0b1010, 1), (2, 384, 2564, 4, 2, 0b10, 1), (3, 192, 300, 8, 1, 0, 0),
+                                   (1, 96, 4960, 16, 4, 0b0110, 1)],
+                         ids=["2x768x1200xN16", "2x384x2564xN4", "3x192x300xN8", "1x96x4960xN16-segments"])
 def test_quad_row_backward_geometries_against_oracle(shape, opts):
     """csrc/scan_bwd4.hip (ckpt_pitch 160) in every launch geometry -- waves per workgroup, states per barrier, row
-    blocks, L2 touches on/off -- against the CPU oracle: all seven gradients, reversed groups, shared u / dout rows."""
+    blocks, L2 touches on/off, two workgroups per CU, sequence segments (forced and automatic: the few-row shape) --
+    against the CPU oracle: all seven gradients, reversed groups, shared u / dout rows."""
     batch, KD, L, N, G, mask, ush = shape
     u, delta, A, B, C, D, bias, dout = _model_like(batch, KD, L, N, G, seed=23)
     rpg = KD // G

@@ -19,7 +19,7 @@ from sigma_amd import _capi                                    # noqa: E402
 from sigma_amd import selective_scan_cuda_core as core         # noqa: E402
 from tools.scan_bench import SHAPES, make, time_call, bwd_bytes   # noqa: E402
 
-OPTS = ("bwd_gen", "bwd_items", "bwd_waves", "bwd_nb", "bwd_slab2", "bwd_rb", "bwd_sb", "bwd_touch", "bwd_wgs")
+OPTS = ("bwd_gen", "bwd_items", "bwd_waves", "bwd_nb", "bwd_slab2", "bwd_rb", "bwd_sb", "bwd_touch", "bwd_wgs", "bwd_seg")
 
 
 def bwd_plan(shape, pitch):
