@@ -244,7 +244,15 @@ class PatchMerging2D(nn.Module):
         H, W = x.shape[-3], x.shape[-2]
         if (H % 2) or (W % 2):
             x = F.pad(x, (0, 0, 0, W % 2, 0, H % 2))
-        x = torch.cat([x[..., 0::2, 0::2, :], x[..., 1::2, 0::2, :], x[..., 0::2, 1::2, :], x[..., 1::2, 1::2, :]], -1)
+        # the reference's cat of the four strided slices [(h even, w even), (h odd, w even), (h even, w odd), (h odd, w odd)]
+        # (vmamba.py:627-631) is one permutation: channel block index = 2 * (w parity) + (h parity).  As a single
+        # permute + copy its backward is one copy too, instead of 4 x (zero fill + strided copy) + 3 adds
+        # (SliceBackward0: 3.1 ms per step in profiles/r02_aten_tail_by_node.txt).
+        lead = x.shape[:-3]
+        Hp, Wp, C = x.shape[-3], x.shape[-2], x.shape[-1]
+        x = x.reshape(*lead, Hp // 2, 2, Wp // 2, 2, C).permute(*range(len(lead)), len(lead), len(lead) + 2, len(lead) + 3,
+                                                                 len(lead) + 1, len(lead) + 4)
+        x = x.reshape(*lead, Hp // 2, Wp // 2, 4 * C)
         return self.reduction(self.norm(x))
 
 
@@ -386,7 +394,8 @@ class CrossMambaFusion_SS2D_SSM(nn.Module):
         B, H, W, _ = x_rgb.shape
         both = torch.cat([self.in_proj(x_rgb), self.in_proj_modalx(x_e)], dim=0)      # shared conv: one launch
         both = _conv_act(self.conv2d, self.act, both.permute(0, 3, 1, 2).contiguous()).flatten(2)  # (2B, d, L)
-        y_rgb, y_e = self.CMA_ssm(both[:B], both[B:])
+        b_rgb, b_e = both.split(B, dim=0)             # split: the backward is ONE cat (two slices: 2 x zero fill + copy + add)
+        y_rgb, y_e = self.CMA_ssm(b_rgb, b_e)
         y_rgb = self.dropout_rgb(self.out_proj_rgb(y_rgb.view(B, H, W, -1)))
         y_e = self.dropout_e(self.out_proj_e(y_e.view(B, H, W, -1)))
         return y_rgb, y_e
@@ -454,13 +463,15 @@ class ConMB_SS2D(nn.Module):
         if _FUSED_SS2D and seq.is_cuda:
             # the flipped direction is read backwards by the kernel: no flipped copies of seq / x_dbl / ys
             p4 = p.view(B, 2, c, L)
-            dts = torch.matmul(self.dt_projs_weight.unsqueeze(0), p4[:, :, :R])  # (B, 2, d, L)
-            ys = selective_scan_ext(seq, dts.reshape(B, 2 * d, L), -torch.exp(self.A_logs.float()), p4[:, :, R:R + N],
-                                    p4[:, :, R + N:], self.Ds.float(), self.dt_projs_bias.float().reshape(-1),
+            p_dt, p_b, p_c = torch.split(p4, [R, N, N], dim=2)                   # views; backward = one cat
+            dts = torch.matmul(self.dt_projs_weight.unsqueeze(0), p_dt)          # (B, 2, d, L)
+            ys = selective_scan_ext(seq, dts.reshape(B, 2 * d, L), -torch.exp(self.A_logs.float()), p_b,
+                                    p_c, self.Ds.float(), self.dt_projs_bias.float().reshape(-1),
                                     rev_mask=0b10, u_gshift=1).view(B, 2, d, L)
             y = ys[:, 0] + ys[:, 1]
-            y_rgb = self.out_norm1(y[..., :HW].transpose(1, 2).reshape(B, H, W, d))
-            y_e = self.out_norm2(y[..., HW:].transpose(1, 2).reshape(B, H, W, d))
+            y1, y2 = y.split(HW, dim=-1)
+            y_rgb = self.out_norm1(y1.transpose(1, 2).reshape(B, H, W, d))
+            y_e = self.out_norm2(y2.transpose(1, 2).reshape(B, H, W, d))
             return y_rgb, y_e
         x_dbl = torch.stack([p[:, :c], p[:, c:].flip(-1)], dim=1)                # (B, 2, c, L)
         dts, Bs, Cs = torch.split(x_dbl, [R, N, N], dim=2)
