@@ -370,7 +370,7 @@ PlanF4 plan_fwd4(const sigma_scan_fwd_params* p, bool vec) {
     std::memset(&pl, 0, sizeof(pl));
     if (p->ckpt_pitch != SIGMA_SCAN_CKPT_PITCH_160 || g_opt_fwd_gen.load() == 1) return pl;
     const int N = p->dstate;
-    if (N != 2 && N != 4 && N != 8 && N != 16) return pl;
+    if (N != 4 && N != 8 && N != 16) return pl;                       // the state counts the model uses (and the tests cover)
     if (!glds_ok(p, vec)) return pl;
     const int rpg = p->dim / p->n_groups;
     if (rpg % 4 != 0) return pl;
@@ -403,7 +403,7 @@ Plan4 plan_bwd4(const sigma_scan_fwd_params* p, bool vec) {
     std::memset(&pl, 0, sizeof(pl));
     if (p->ckpt_pitch != SIGMA_SCAN_CKPT_PITCH_160) return pl;
     const int N = p->dstate;
-    if (N != 2 && N != 4 && N != 8 && N != 16) return pl;
+    if (N != 4 && N != 8 && N != 16) return pl;                       // the state counts the model uses (and the tests cover)
     if (!glds_ok(p, vec)) return pl;                                  // f32, aligned B/C: the kernel stages by LDS-DMA only
     const int rpg = p->dim / p->n_groups;
     if (rpg % 4 != 0) return pl;
@@ -647,7 +647,7 @@ int sigma_selective_scan_bwd(const sigma_scan_bwd_params* q, void* stream) {
         // B/C alignment is part of the plan: the caller chose the pitch at forward time with the same tensors
         p4 = plan_bwd4(p, vec_ok_fwd(p, false));
         if (!p4.ok)
-            return fail(SIGMA_ERR_BAD_SHAPE, "ckpt_pitch 160 needs f32 IO, 16-byte aligned B/C, dstate in {2,4,8,16} and rows per group divisible by 4");
+            return fail(SIGMA_ERR_BAD_SHAPE, "ckpt_pitch 160 needs f32 IO, 16-byte aligned B/C, dstate in {4,8,16} and rows per group divisible by 4");
     }
     const Plan3 p3 = p4.ok ? Plan3{} : plan_bwd3(p, vec);
     Plan2 p2;

@@ -20,7 +20,7 @@
 //   * per-row scalars of a state (A, checkpoint, reverse carry) live in lane vectors (lane 16*row + n) and
 //     are broadcast inside their DPP row with ds_bpermute_b32; the per-state results (outgoing carry, dA)
 //     are collected with a select + row rotate.
-// Needs: f32 IO, B/C eligible for global_load_lds, dstate in {2,4,8,16}, ckpt_pitch 160, rows per group
+// Needs: f32 IO, B/C eligible for global_load_lds, dstate in {4,8,16}, ckpt_pitch 160, rows per group
 // divisible by 4*W.  Everything else stays on scan_bwd2.hip / scan_bwd.hip.
 #include "scan_device.h"
 #include "scan_launch.h"

@@ -91,14 +91,14 @@ def _ptr(t: Optional[torch.Tensor]):
 
 def quad_backward_ok(u, delta, B, C) -> bool:
     """True when the quad-row backward (csrc/scan_bwd4.hip, ckpt_pitch 160) can take these operands: f32 IO,
-    dstate in {2, 4, 8, 16}, rows per group divisible by 4, L % 4 == 0, 16-byte aligned u / delta / B / C with
+    dstate in {4, 8, 16}, rows per group divisible by 4, L % 4 == 0, 16-byte aligned u / delta / B / C with
     strides that are multiples of 4 elements (plan_bwd4 in csrc/capi.hip is the authority and fails loudly)."""
     if any(t.dtype != torch.float32 for t in (u, delta, B, C)):
         return False
     Bv = B if B.dim() == 4 else B.unsqueeze(1)
     Cv = C if C.dim() == 4 else C.unsqueeze(1)
     n_groups, dstate, seqlen = Bv.shape[1], Bv.shape[2], Bv.shape[3]
-    if dstate not in (2, 4, 8, 16) or seqlen % 4 != 0 or delta.shape[1] % (4 * n_groups) != 0:
+    if dstate not in (4, 8, 16) or seqlen % 4 != 0 or delta.shape[1] % (4 * n_groups) != 0:
         return False
     for t in (u, delta, Bv, Cv):
         if t.data_ptr() % 16 != 0 or t.stride(-1) != 1 or any(s % 4 != 0 for s in t.stride()[:-1]):
