@@ -70,8 +70,15 @@ def wrap_ddp(model: nn.Module, device: torch.device) -> nn.Module:
     if not _distributed():
         return model
     ids = [device.index] if device.type == "cuda" else None
+    import os
+    # gradient_as_bucket_view: gradients live in the all-reduce buckets (no grad -> bucket copy, 279 MB per step for
+    # sigma_small); bucket size: xGMI rings are per-link bound, fewer and larger all-reduces amortise their latency.
+    # Environment knobs for A/B runs only.
+    kw = dict(gradient_as_bucket_view=os.environ.get("SIGMA_DDP_VIEW", "1") == "1",
+              bucket_cap_mb=int(os.environ.get("SIGMA_DDP_BUCKET_MB", "25")),
+              static_graph=os.environ.get("SIGMA_DDP_STATIC", "0") == "1")
     return nn.parallel.DistributedDataParallel(model, device_ids=ids, output_device=ids[0] if ids else None,
-                                               find_unused_parameters=False)
+                                               find_unused_parameters=False, **kw)
 
 
 def make_step(net: nn.Module, opt, batch: Tuple[torch.Tensor, ...]) -> Callable[[], torch.Tensor]:
