@@ -66,8 +66,11 @@ enum sigma_status {
  * ceil(seqlen/1280), so it always fits).  Callers that allocate x themselves may ask for a fine
  * pitch 640 or 320 (ckpt_pitch field) with x_row_stride >= ceil(seqlen/pitch)*N: the backward then
  * needs no forward sweep at all (its tiles are 640 / 320 elements) and runs the second-generation
- * kernel, whose workgroups accumulate dB/dC over many rows before touching memory.  Unused slots
- * are not written. */
+ * kernel, whose workgroups accumulate dB/dC over many rows before touching memory.  Pitch 160 selects
+ * the quad-row kernels (scan_fwd4.hip / scan_bwd4.hip: a wave = 4 channel rows x 16 lanes x 10 positions; with few rows
+ * the backward additionally splits the sequence into segments): f32 IO, dstate in {4, 8, 16}, rows per group divisible
+ * by 4, seqlen % 4 == 0, 16-byte aligned operands -- the backward fails with SIGMA_ERR_BAD_SHAPE otherwise (the forward
+ * falls back to the 64-lane kernel, which writes the same checkpoints).  Unused slots are not written. */
 #define SIGMA_SCAN_CHUNK 2048
 #define SIGMA_SCAN_CKPT_PITCH 1280
 #define SIGMA_SCAN_CKPT_PITCH_FINE 640
@@ -96,7 +99,7 @@ typedef struct sigma_scan_fwd_params {
      *      flip share one physical copy of x. */
     uint32_t rev_group_mask;
     int32_t u_group_shift;
-    int32_t ckpt_pitch;        /* 0 = SIGMA_SCAN_CKPT_PITCH (1280); 640 / 320 = fine checkpoints (see above) */
+    int32_t ckpt_pitch;        /* 0 = SIGMA_SCAN_CKPT_PITCH (1280); 640 / 320 / 160 = fine checkpoints (see above) */
     int32_t param_group_swap;  /* 1 (needs n_groups == 4): A, D, delta_bias and dA, dD, ddelta_bias keep the REFERENCE's direction
                                   order k = [row, col, row reversed, col reversed] (vmamba.py:84-89) while the sequence
                                   operands use the kernel's group order g = 2*order + reversed: group g reads / writes the
@@ -160,8 +163,9 @@ int sigma_selective_scan_fwd(const sigma_scan_fwd_params *params, void *stream);
 /* Backward: du, ddelta, dB, dC written; dA, dD, ddelta_bias accumulated (+=). */
 int sigma_selective_scan_bwd(const sigma_scan_bwd_params *params, void *stream);
 
-/* Scratch bytes sigma_selective_scan_bwd needs for this problem under the current options
- * (0 when one workgroup covers a whole (batch, group)); negative = invalid params. */
+/* Scratch bytes sigma_selective_scan_bwd needs for this problem under the current options: the per-workgroup dB/dC
+ * partials (0 when one workgroup covers a whole (batch, group)) plus the segment summaries of a split sequence;
+ * negative = invalid params. */
 int64_t sigma_scan_bwd_workspace_bytes(const sigma_scan_bwd_params *params);
 
 /* Thread-local description of the last non-zero status returned on this thread. */
@@ -184,8 +188,11 @@ int sigma_scan_abi_version(void);
  *   "bwd_touch"                L2 warm-up of the next row step's u/delta/dout lines: 1 = on, 2 = off, 0 = on in the
  *                              quad-row backward (touches 3 states ahead: -3..-6 %), off in the second generation (there
  *                              a whole row step ahead: every line fetched twice for 1 %, profiles/r02_pmc_enc_s2_b16.txt)
- *   "fwd_gen"                  1 = never the quad-row forward (scan_fwd4.hip), which serves ckpt_pitch 160 otherwise
+ *   "fwd_gen"                  1 = never the quad-row forward (scan_fwd4.hip), which serves ckpt_pitch 160 with >= 8192
+ *                              rows otherwise; 2 = also with fewer rows
  *   "bwd_sb"                   quad-row backward (ckpt_pitch 160): states per barrier {1, 2, 4, 8}; 0 = 2
+ *   "bwd_seg"                  quad-row backward: sequence segments {2,3,4,6,8,12}; 1 = never split; 0 = cost model
+ *   "bwd_wgs"                  quad-row backward: 2 = two workgroups of <= 8 waves per CU (A/B knob)
  * Returns SIGMA_ERR_BAD_OPTION for unknown names / unsupported values. */
 int sigma_scan_set_option(const char *name, int value);
 int sigma_scan_get_option(const char *name);
