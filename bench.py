@@ -63,6 +63,12 @@ def parse():
     ap.add_argument("--split-gemm", action="store_true",
                     help="nn.Linear GEMMs as split-operand bf16 MFMA GEMMs (sigma_amd/split_linear.py: 4e-6 rms error per GEMM, "
                          "reported as config.gemm; the default and headline stay fp32 GEMMs)")
+    ap.add_argument("--gemm", default="", choices=["", "fp32", "split3"],
+                    help="nn.Linear GEMMs: split3 = hand-written split-operand bf16 MFMA kernels (csrc/gemm_split.hip), fp32 = vendor "
+                         "fp32 GEMMs; default: sigma_amd.gemm.gemm_mode()")
+    ap.add_argument("--strict-tuned", action="store_true",
+                    help="exit with an error when PyTorch rejects the committed TunableOp GEMM table (default: warn on stderr and "
+                         "report config.tuned_gemms = false)")
     ap.add_argument("--cpu-budget", type=float, default=20.0, help="(unused: the CPU sample is fixed) kept for compatibility")
     ap.add_argument("--kernel-report", default="", help="write the per-kernel-shape table (json) here")
     return ap.parse_args()
@@ -221,6 +227,8 @@ def main():
 
     if a.split_gemm:
         os.environ["SIGMA_SPLIT_GEMM"] = "1"
+    if a.gemm:
+        os.environ["SIGMA_GEMM"] = a.gemm
     from sigma_amd import selective_scan_cuda_core as core
     from sigma_amd.models.builder import EncoderDecoder
 
@@ -266,10 +274,23 @@ def main():
         gstep, _ = ts.make_graphed_step(net, opt, (rgb, mx, label))
         elapsed, loss = ts.timed_steps(gstep, a.steps, a.warmup, dev)
     else:
-        eager_scan_steps = a.steps
-        elapsed, loss = ts.timed_steps(step, a.steps, a.warmup, dev, on_timed_start=start_timers)
+        # the timed region runs WITHOUT the per-launch HIP events (two events around each of ~270 scan launches per step
+        # perturb what they measure); the kernel table comes from two extra eager steps afterwards
+        elapsed, loss = ts.timed_steps(step, a.steps, a.warmup, dev)
+        eager_scan_steps = 2
+        start_timers()
+        step(); step(); torch.cuda.synchronize()
         timer.enabled = False
 
+    from sigma_amd.tuning import tuned_gemms_active
+    tuned = tuned_gemms_active()
+    if not tuned and os.environ.get("SIGMA_TUNED_GEMMS", "1") != "0":
+        msg = ("bench.py: the committed TunableOp GEMM table (sigma_amd/tuning/tunableop_mi355x.csv) is NOT active -- PyTorch "
+               "rejected it (ROCm / hipBLASLt / rocBLAS version validators) or it is missing; library-default GEMM solutions "
+               "are ~17 % slower on this step")
+        if a.strict_tuned:
+            raise SystemExit(msg)
+        print(msg, file=sys.stderr, flush=True)
     if rank == 0:
         table = timer.table()
         rows = []
@@ -312,7 +333,8 @@ def main():
                     config=dict(workload=f"{a.backbone} training step (fwd+bwd+AdamW), RGB-X pairs {a.height}x{a.width}, "
                                          f"{a.classes} classes, fp32", per_gpu_batch=a.batch,
                                 global_batch=a.batch * world, parallelism=f"dp{world}", hip_graph=use_graph,
-                                gemm=("bf16x3 split-operand MFMA, fp32 accumulate/output" if a.split_gemm else "fp32"),
+                                tuned_gemms=bool(tuned),
+                                gemm=getattr(model, "gemm_mode", "fp32"),
                                 loss=round(float(loss.item()), 4)),
                     roofline=roof, roofline_fwd=roof_fwd, cpu_baseline=cpu)
         print(json.dumps(line), flush=True)

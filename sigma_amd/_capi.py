@@ -108,6 +108,21 @@ class LayerNormParams(ctypes.Structure):
     ]
 
 
+class GemmParams(ctypes.Structure):
+    """mirror of sigma_gemm_params (include/sigma_gemm.h)"""
+    _fields_ = [
+        ("M", ctypes.c_int64), ("N", ctypes.c_int32), ("K", ctypes.c_int32),
+        ("A", ctypes.c_void_p), ("Bt", ctypes.c_void_p), ("C", ctypes.c_void_p), ("bias", ctypes.c_void_p),
+        ("lda", ctypes.c_int64), ("ldb", ctypes.c_int64), ("ldc", ctypes.c_int64),
+        ("accumulate", ctypes.c_int32), ("batch", ctypes.c_int32),
+        ("strideA", ctypes.c_int64), ("strideB", ctypes.c_int64), ("strideC", ctypes.c_int64),
+        ("a_mod", ctypes.c_int32), ("reserved_", ctypes.c_int32),
+    ]
+
+
+# every symbol include/sigma_gemm.h declares
+GEMM_SYMBOLS = ("sigma_gemm_nt_split3", "sigma_gemm_nn_split3", "sigma_gemm_tn_split3")
+
 # every symbol include/sigma_ops.h declares
 OPS_SYMBOLS = ("sigma_dwconv3x3_silu_fwd", "sigma_dwconv3x3_silu_bwd", "sigma_cross_merge_nhwc", "sigma_cross_split_nhwc",
                "sigma_layernorm_fwd", "sigma_layernorm_bwd", "sigma_layernorm_bwd_partial_rows", "sigma_transpose2d",
@@ -180,6 +195,10 @@ def load() -> ctypes.CDLL:
             st = (MergeParams if "cross_" in name else LayerNormParams if "layernorm" in name else
                   TransposeParams if "transpose" in name else DwConvParams)
             fn.argtypes = [P(st), ctypes.c_void_p]
+        fn.restype = ctypes.c_int
+    for name in GEMM_SYMBOLS:
+        fn = getattr(lib, name)
+        fn.argtypes = [P(GemmParams), ctypes.c_void_p]
         fn.restype = ctypes.c_int
     if lib.sigma_scan_abi_version() != SIGMA_SCAN_ABI_VERSION:
         raise SigmaHipUnavailable(

@@ -107,15 +107,19 @@ def quad_backward_ok(u, delta, B, C) -> bool:
 
 
 def _fine_pitch(x, seqlen: int, dstate: int, ckpt_pitch: int) -> int:
-    """Pitch of a fine-checkpoint x (B, dim, ceil(L/pitch) * N): the caller's ``ckpt_pitch`` if given,
-    else inferred from the slot count (640 wins when both fit, i.e. for L <= 320)."""
+    """Pitch of a fine-checkpoint x (B, dim, ceil(L/pitch) * N): the caller's ``ckpt_pitch`` if given, else
+    inferred from the slot count -- which is only possible when exactly one pitch of {640, 320, 160} gives
+    that count (a single slot fits all three for L <= 160): an ambiguous x must come with its pitch."""
     if ckpt_pitch:
         return int(ckpt_pitch)
     slots = x.size(2) // max(dstate, 1)
-    for pitch in (_capi.SIGMA_SCAN_CKPT_PITCH_FINE, _capi.SIGMA_SCAN_CKPT_PITCH_320, _capi.SIGMA_SCAN_CKPT_PITCH_160):
-        if slots == max((seqlen + pitch - 1) // pitch, 1):
-            return pitch
-    raise RuntimeError("fine-checkpoint x must be (batch, dim, ceil(L/640)*dstate) or (batch, dim, ceil(L/320)*dstate)")
+    match = [pitch for pitch in (_capi.SIGMA_SCAN_CKPT_PITCH_FINE, _capi.SIGMA_SCAN_CKPT_PITCH_320, _capi.SIGMA_SCAN_CKPT_PITCH_160)
+             if slots == max((seqlen + pitch - 1) // pitch, 1)]
+    if len(match) == 1:
+        return match[0]
+    if not match:
+        raise RuntimeError("fine-checkpoint x must be (batch, dim, ceil(L/pitch)*dstate) with pitch 640, 320 or 160")
+    raise RuntimeError(f"fine-checkpoint x with {slots} slot(s) fits the pitches {match}: pass ckpt_pitch (the pitch given to fwd_ext)")
 
 
 def _fill_fwd(fp: _capi.FwdParams, u, delta, A, B, C, D_, delta_bias_, out, x, delta_softplus, sizes,
@@ -125,6 +129,8 @@ def _fill_fwd(fp: _capi.FwdParams, u, delta, A, B, C, D_, delta_bias_, out, x, d
     fp.param_group_swap = int(param_swap)
     if x is not None and x.dim() == 3:              # fine checkpoints: (B, dim, ceil(L/pitch) * N)
         fp.ckpt_pitch, fp.x_row_stride = _fine_pitch(x, seqlen, dstate, ckpt_pitch), x.stride(1)
+    elif x is None and ckpt_pitch:                  # inference: no checkpoints are written, the pitch still selects the kernel
+        fp.ckpt_pitch = int(ckpt_pitch)
     fp.batch, fp.dim, fp.seqlen, fp.dstate, fp.n_groups = batch, dim, seqlen, dstate, n_groups
     fp.n_chunks = (seqlen + _capi.SIGMA_SCAN_CHUNK - 1) // _capi.SIGMA_SCAN_CHUNK
     fp.io_dtype = _DTYPES[u.dtype]
@@ -158,7 +164,8 @@ def fwd_ext(u, delta, A, B, C, D_, delta_bias_, delta_softplus, nrows: int = 1, 
     as (B, dim, ceil(L/640) * N) with one state checkpoint per 640 elements (include/sigma_scan.h),
     which spares ``bwd_ext`` its forward sweep and lets it run the second-generation kernel
     (csrc/scan_bwd2.hip); ``ckpt_pitch`` = 640 / 320 selects the pitch explicitly (320: 320-element
-    backward tiles).  Such an x is only valid for ``bwd_ext``.  ``param_swap`` = 1 (four groups): A, D,
+    backward tiles), 160 the quad-row kernels (csrc/scan_fwd4.hip / scan_bwd4.hip).  Such an x is only valid for
+    ``bwd_ext`` called with the same ``ckpt_pitch``.  ``need_x=False`` (inference): x comes back empty.  ``param_swap`` = 1 (four groups): A, D,
     delta_bias stay in the reference's direction order while the sequence operands use the kernel's group
     order (include/sigma_scan.h, param_group_swap)."""
     lib = _capi.load()
@@ -170,7 +177,9 @@ def fwd_ext(u, delta, A, B, C, D_, delta_bias_, delta_softplus, nrows: int = 1, 
         ckpt_pitch = _capi.SIGMA_SCAN_CKPT_PITCH_FINE
     _check(ckpt_pitch in (0, _capi.SIGMA_SCAN_CKPT_PITCH_FINE, _capi.SIGMA_SCAN_CKPT_PITCH_320, _capi.SIGMA_SCAN_CKPT_PITCH_160),
            "ckpt_pitch must be 0, 640, 320 or 160")
-    if ckpt_pitch:
+    if not need_x:                                                  # eval / no_grad: nothing is checkpointed
+        x = torch.empty((0,), device=u.device, dtype=torch.float32)
+    elif ckpt_pitch:
         ncp = (seqlen + ckpt_pitch - 1) // ckpt_pitch
         x = torch.empty((batch, dim, max(ncp, 1) * dstate), device=u.device, dtype=torch.float32)
     else:

@@ -213,11 +213,12 @@ class SelectiveScanExtFn(torch.autograd.Function):
         B = B.float() if B.stride(-1) == 1 else B.float().contiguous()
         C = C.float() if C.stride(-1) == 1 else C.float().contiguous()
         A, D, delta_bias = A.float().contiguous(), D.float().contiguous(), delta_bias.float().contiguous()
+        pitch = ckpt_pitch_for(u.shape[-1], A.shape[1], delta.shape[0] * delta.shape[1], _core.quad_backward_ok(u, delta, B, C))
         out, ck = _core.fwd_ext(u, delta, A, B, C, D, delta_bias, True, rev_mask=rev_mask, u_gshift=u_gshift,
-                                need_x=any(ctx.needs_input_grad),
-                                ckpt_pitch=ckpt_pitch_for(u.shape[-1], A.shape[1], delta.shape[0] * delta.shape[1], _core.quad_backward_ok(u, delta, B, C)))
+                                need_x=any(ctx.needs_input_grad), ckpt_pitch=pitch)
         ctx.save_for_backward(u, delta, A, B, C, D, delta_bias, ck)
         ctx.ext = (int(rev_mask), int(u_gshift))
+        ctx.pitch = pitch                                     # the backward tile IS the forward's checkpoint pitch
         return out
 
     @staticmethod
@@ -225,13 +226,14 @@ class SelectiveScanExtFn(torch.autograd.Function):
         u, delta, A, B, C, D, delta_bias, ck = ctx.saved_tensors
         rev_mask, sh = ctx.ext
         du, ddelta, dA, dB, dC, dD, dbias = _core.bwd_ext(u, delta, A, B, C, D, delta_bias, dout.float().contiguous(), ck,
-                                                          True, rev_mask=rev_mask, u_gshift=sh)
+                                                          True, rev_mask=rev_mask, u_gshift=sh, ckpt_pitch=ctx.pitch)
         if sh:
             Bsz, dim, L = du.shape
             G = B.shape[1]
             rpg = dim // G
             du = du.view(Bsz, G >> sh, 1 << sh, rpg, L).sum(2).reshape(Bsz, dim >> sh, L)
-        return du, ddelta, dA, dB, dC, dD, dbias, None, None
+        # dA / dD / dbias are views of ONE zero-filled buffer (bwd_ext): hand autograd tensors that own their storage
+        return du, ddelta, dA.clone(), dB, dC, dD.clone(), dbias.clone(), None, None
 
 
 def selective_scan_ext(u, delta, A, B, C, D, delta_bias, rev_mask=0, u_gshift=0):
@@ -310,8 +312,10 @@ class SS2DCoreFn(torch.autograd.Function):
         Bv, Cv = p4[:, :, R:R + N], p4[:, :, R + N:]
         need_x = any(ctx.needs_input_grad)
         u2, dl2 = xs2.view(B, 2 * d, L), delta.view(B, 4 * d, L)
+        pitch = ckpt_pitch_for(L, N, B * 4 * d, _core.quad_backward_ok(u2, dl2, Bv, Cv))
         out, ck = _core.fwd_ext(u2, dl2, A, Bv, Cv, Dp, bias, True, rev_mask=_REV_MASK, u_gshift=1, need_x=need_x,
-                                ckpt_pitch=ckpt_pitch_for(L, N, B * 4 * d, _core.quad_backward_ok(u2, dl2, Bv, Cv)), param_swap=1)
+                                ckpt_pitch=pitch, param_swap=1)
+        ctx.pitch = pitch
         y = cross_merge_nhwc(out.view(B, 4, d, L), H, W)                       # (B, H, W, d)
         ctx.save_for_backward(xs2, p4, delta, A, Dp, bias, ck, Wst, dtw)
         ctx.dims = (B, d, H, W, c, R, N)
@@ -327,7 +331,8 @@ class SS2DCoreFn(torch.autograd.Function):
         Bv, Cv = p4[:, :, R:R + N], p4[:, :, R + N:]
         du, ddelta, dA, _, _, dD, dbias = _core.bwd_ext(
             xs2.view(B, 2 * d, L), delta.view(B, 4 * d, L), A, Bv, Cv, Dp, bias, g2.view(B, 2 * d, L), ck, True,
-            rev_mask=_REV_MASK, u_gshift=1, dout_gshift=1, dB_out=dp4[:, :, R:R + N], dC_out=dp4[:, :, R + N:], param_swap=1)
+            rev_mask=_REV_MASK, u_gshift=1, dout_gshift=1, dB_out=dp4[:, :, R:R + N], dC_out=dp4[:, :, R + N:], param_swap=1,
+            ckpt_pitch=ctx.pitch)
         ddelta4 = ddelta.view(B, 4, d, L)
         # dt_proj: delta = dtw @ p4[:R]
         dp4[:, :, :R] = torch.matmul(dtw.transpose(1, 2).unsqueeze(0), ddelta4)
@@ -340,8 +345,8 @@ class SS2DCoreFn(torch.autograd.Function):
         d_xproj = _perm4(dWst.view(4, c, d))                                   # the permutation is its own inverse
         d_dtw = _perm4(d_dtw)
         dA_logs = dA * A                                                       # A = -exp(A_logs); reference order already
-        dDs = dD
-        dbias = dbias.view(4, d)
+        dDs = dD.clone()                                                       # dD / dbias: views of one shared buffer
+        dbias = dbias.clone().view(4, d)
         return dxs2, None, None, d_xproj, d_dtw, dbias, dA_logs, dDs
 
 

@@ -21,7 +21,8 @@ _state = {"enabled": None}
 
 
 def enable_tuned_gemms(table: str = TABLE) -> bool:
-    """Idempotent; returns True when the lookup table is active."""
+    """Idempotent; returns True when the lookup was switched on (see ``tuned_gemms_active`` for whether PyTorch
+    accepted the table)."""
     if _state["enabled"] is not None:
         return _state["enabled"]
     ok = False
@@ -31,9 +32,31 @@ def enable_tuned_gemms(table: str = TABLE) -> bool:
             import torch.cuda.tunable as tun
             tun.set_filename(table)
             tun.tuning_enable(False)          # look up only; unknown shapes use the library default
+            if hasattr(tun, "write_file_on_exit"):
+                tun.write_file_on_exit(False)     # the committed table is never rewritten by a run
             tun.enable(True)
             ok = True
+            try:                              # explicit read: False when the validators in the file reject this stack
+                _state["accepted"] = bool(tun.read_file(table))
+            except Exception:                 # noqa: BLE001
+                _state["accepted"] = None
     except Exception as e:                    # noqa: BLE001 -- an optimisation, never a reason to fail
         print(f"sigma_amd.tuning: tuned GEMM table not used ({e})")
     _state["enabled"] = ok
     return ok
+
+
+def tuned_gemms_active() -> bool:
+    """True when the lookup is on AND PyTorch accepted the committed table, i.e. it holds results after the
+    validators (ROCm / hipBLASLt / rocBLAS versions recorded in the file) were checked.  TunableOp reads the file
+    lazily at the first GEMM, so call this after a step has run.  A rejected table costs ~17 % of the batch-8 step
+     and used to go unnoticed; bench.py reports this flag as config.tuned_gemms."""
+    if not _state["enabled"]:
+        return False
+    try:
+        import torch.cuda.tunable as tun
+        if _state.get("accepted") is False:
+            return False
+        return tun.is_enabled() and len(tun.get_results()) > 0
+    except Exception:                         # noqa: BLE001
+        return False

@@ -29,6 +29,11 @@ def test_exports_every_declared_symbol():
     assert declared_ops == set(_capi.OPS_SYMBOLS), declared_ops ^ set(_capi.OPS_SYMBOLS)
     for name in declared_ops:
         assert getattr(lib, name) is not None
+    gemm = open(os.path.join(ROOT, "include", "sigma_gemm.h")).read()
+    declared_gemm = set(re.findall(r"^\s*int\s+(sigma_\w+)\s*\(", gemm, flags=re.M))
+    assert declared_gemm == set(_capi.GEMM_SYMBOLS), declared_gemm ^ set(_capi.GEMM_SYMBOLS)
+    for name in declared_gemm:
+        assert getattr(lib, name) is not None
 
 
 def test_struct_layout_matches_header(tmp_path):
@@ -38,13 +43,14 @@ def test_struct_layout_matches_header(tmp_path):
     lines = []
     structs = (("sigma_scan_fwd_params", _capi.FwdParams), ("sigma_scan_bwd_params", _capi.BwdParams),
                ("sigma_dwconv_params", _capi.DwConvParams), ("sigma_merge_params", _capi.MergeParams),
-               ("sigma_layernorm_params", _capi.LayerNormParams), ("sigma_transpose_params", _capi.TransposeParams))
+               ("sigma_layernorm_params", _capi.LayerNormParams), ("sigma_transpose_params", _capi.TransposeParams),
+               ("sigma_gemm_params", _capi.GemmParams))
     for cname, cls in structs:
         lines.append(f'printf("%s %zu\\n", "{cname}", sizeof({cname}));')
         for fname, _ in cls._fields_:
             lines.append(f'printf("%s.%s %zu\\n", "{cname}", "{fname}", offsetof({cname}, {fname}));')
     src = tmp_path / "layout.c"
-    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "sigma_scan.h"\n#include "sigma_ops.h"\nint main(void){' + "".join(lines) + "return 0;}")
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "sigma_scan.h"\n#include "sigma_ops.h"\n#include "sigma_gemm.h"\nint main(void){' + "".join(lines) + "return 0;}")
     exe = tmp_path / "layout"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     got = dict(l.split() for l in subprocess.check_output([str(exe)], text=True).splitlines())

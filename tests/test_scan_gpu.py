@@ -474,6 +474,47 @@ def test_quad_row_backward_geometries_against_oracle(shape, opts):
                                    msg=lambda m, name=name: f"d{name}: {m}")
 
 
+FULL_LAUNCHES = [
+    # (batch, KD, L, N, G, rev_mask, u_gshift): whole launches of the sigma_small training step at batch 8 (2 x 8 encoder
+    # images): the dominant one (encoder stage 2) and the SURVEY headline shape at the same batch
+    (16, 3072, 1200, 16, 4, 0b1010, 1),
+    (16, 768, 19200, 16, 4, 0b1010, 1),
+]
+
+
+@pytest.mark.parametrize("shape", FULL_LAUNCHES, ids=["16x3072x1200xN16", "16x768x19200xN16"])
+def test_full_size_step_launches_against_oracle(shape):
+    """The benchmarked launches AT THEIR REAL SIZE, with the pitch / kernels the fused model path picks automatically
+    (ckpt_pitch_for -> 160: scan_fwd4 + scan_bwd4 with the planner's own geometry), forward and all seven gradients
+    against the CPU oracle (OpenMP; a few seconds per launch)."""
+    from sigma_amd.ss2d_fused import ckpt_pitch_for
+    batch, KD, L, N, G, mask, ush = shape
+    u, delta, A, B, C, D, bias, dout = _model_like(batch, KD, L, N, G, seed=31)
+    rpg = KD // G
+    keep = lambda t: torch.cat([t[:, g * rpg:(g + 1) * rpg] for g in range(0, G, 1 << ush)], dim=1).contiguous()
+    full = lambda t: torch.cat([t[:, (g >> ush) * rpg:((g >> ush) + 1) * rpg] for g in range(G)], dim=1)
+    u_h, g_h = keep(u), keep(dout)
+    u_f, g_f = full(u_h), full(g_h)
+    core = _core()
+    dev = "cuda"
+    args = [t.to(dev) for t in (u_h, delta, A, B, C, D, bias)]
+    pitch = ckpt_pitch_for(L, N, batch * KD, core.quad_backward_ok(args[0], args[1], args[3], args[4]))
+    assert pitch == 160
+    out, x = core.fwd_ext(*args, True, rev_mask=mask, u_gshift=ush, ckpt_pitch=pitch)
+    grads = core.bwd_ext(*args, g_h.to(dev), x, True, rev_mask=mask, u_gshift=ush, dout_gshift=ush, ckpt_pitch=pitch)
+    revs = [(mask >> g) & 1 for g in range(G)]
+    fr = lambda t: torch.cat([t[:, g * rpg:(g + 1) * rpg].flip(-1) if revs[g] else t[:, g * rpg:(g + 1) * rpg] for g in range(G)], 1)
+    fg = lambda t: torch.stack([t[:, g].flip(-1) if revs[g] else t[:, g] for g in range(G)], 1)
+    so = _oracle()
+    ref = fr(so.selective_scan_oracle(fr(u_f), fr(delta), A, fg(B), fg(C), D, bias, True, acc64=False))
+    torch.testing.assert_close(out.cpu(), ref, rtol=6e-4, atol=2e-3)
+    rg = list(so.selective_scan_oracle_bwd(fr(u_f), fr(delta), A, fg(B), fg(C), D, bias, fr(g_f), True))
+    rg[0], rg[1], rg[3], rg[4] = fr(rg[0]), fr(rg[1]), fg(rg[3]), fg(rg[4])
+    for name, g, r in zip(["u", "delta", "A", "B", "C", "D", "bias"], grads, rg):
+        torch.testing.assert_close(g.cpu(), r, rtol=3e-3, atol=2e-3 + 2e-4 * float(r.abs().max()),
+                                   msg=lambda m, name=name: f"d{name}: {m}")
+
+
 def test_quad_row_backward_refuses_what_it_cannot_take():
     """ckpt_pitch 160 with 16-bit IO / odd lengths must fail loudly (no silent fallback), and quad_backward_ok says so first."""
     core = _core()
