@@ -42,7 +42,8 @@ typedef struct sigma_gemm_params {
     int64_t strideA, strideB, strideC;   /* batch strides in floats (0: shared by every problem)    */
     int32_t a_mod;         /* > 0: problem z reads A + (z % a_mod) * strideA (nt / nn): a weight stack
                               shared by groups of problems, e.g. the 2 memory orders x B images of x_proj */
-    int32_t reserved_;
+    int32_t pieces;        /* bf16 pieces per fp32 operand element: 0 or 2 = (hi, lo), three MFMAs per block, ~4e-6 rms
+                              error; 3 = (hi, mid, lo), six MFMAs, ~1e-6 = the accuracy of an fp32 GEMM          */
 } sigma_gemm_params;
 
 /*   sigma_gemm_nt_split3

@@ -116,7 +116,7 @@ class GemmParams(ctypes.Structure):
         ("lda", ctypes.c_int64), ("ldb", ctypes.c_int64), ("ldc", ctypes.c_int64),
         ("accumulate", ctypes.c_int32), ("batch", ctypes.c_int32),
         ("strideA", ctypes.c_int64), ("strideB", ctypes.c_int64), ("strideC", ctypes.c_int64),
-        ("a_mod", ctypes.c_int32), ("reserved_", ctypes.c_int32),
+        ("a_mod", ctypes.c_int32), ("pieces", ctypes.c_int32),
     ]
 
 

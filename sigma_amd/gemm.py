@@ -28,7 +28,7 @@ from . import _capi
 MIN_DIM = 32               # smaller projections are launch / HBM bound either way
 
 
-def _params(M, N, K, A, Bt, C, bias, lda, ldb, ldc, accumulate=False, batch=1, sA=0, sB=0, sC=0, a_mod=0):
+def _params(M, N, K, A, Bt, C, bias, lda, ldb, ldc, accumulate=False, batch=1, sA=0, sB=0, sC=0, a_mod=0, pieces=2):
     p = _capi.GemmParams()
     p.M, p.N, p.K = int(M), int(N), int(K)
     p.A, p.Bt, p.C = A.data_ptr(), Bt.data_ptr(), C.data_ptr()
@@ -37,6 +37,7 @@ def _params(M, N, K, A, Bt, C, bias, lda, ldb, ldc, accumulate=False, batch=1, s
     p.accumulate, p.batch = int(bool(accumulate)), int(batch)
     p.strideA, p.strideB, p.strideC = int(sA), int(sB), int(sC)
     p.a_mod = int(a_mod)
+    p.pieces = int(pieces)
     return p
 
 
@@ -62,8 +63,9 @@ def nt_ok(a: torch.Tensor, bt: torch.Tensor) -> bool:
     return a.shape[1] % 4 == 0 and _rows_ok(a) and _rows_ok(bt)
 
 
-def gemm_nt(a: torch.Tensor, bt: torch.Tensor, bias=None, out=None, accumulate=False) -> torch.Tensor:
-    """out (M, N) (+)= a (M, K) @ bt (N, K)^T (+ bias)"""
+def gemm_nt(a: torch.Tensor, bt: torch.Tensor, bias=None, out=None, accumulate=False, pieces: int = 2) -> torch.Tensor:
+    """out (M, N) (+)= a (M, K) @ bt (N, K)^T (+ bias).  pieces: bf16 pieces per operand element -- 2 = three MFMAs per
+    block (~4e-6 rms error), 3 = six MFMAs (~1e-6, the accuracy of an fp32 GEMM)"""
     _check2d(a, bt)
     M, K = a.shape
     N = bt.shape[0]
@@ -74,7 +76,7 @@ def gemm_nt(a: torch.Tensor, bt: torch.Tensor, bias=None, out=None, accumulate=F
     elif out.stride(1) != 1 or tuple(out.shape) != (M, N):
         raise RuntimeError("gemm_nt: out must be (M, N) with contiguous rows")
     if M and N:
-        _run("sigma_gemm_nt_split3", _params(M, N, K, a, bt, out, bias, a.stride(0), bt.stride(0), out.stride(0), accumulate), a.device)
+        _run("sigma_gemm_nt_split3", _params(M, N, K, a, bt, out, bias, a.stride(0), bt.stride(0), out.stride(0), accumulate, pieces=pieces), a.device)
     return out
 
 
@@ -82,7 +84,7 @@ def nn_ok(a: torch.Tensor, b: torch.Tensor) -> bool:
     return a.shape[1] % 4 == 0 and b.shape[1] % 4 == 0 and _rows_ok(a) and _rows_ok(b)
 
 
-def gemm_nn(a: torch.Tensor, b: torch.Tensor, out=None, accumulate=False) -> torch.Tensor:
+def gemm_nn(a: torch.Tensor, b: torch.Tensor, out=None, accumulate=False, pieces: int = 2) -> torch.Tensor:
     """out (M, N) (+)= a (M, K) @ b (K, N), b read row-major in place"""
     _check2d(a, b)
     M, K = a.shape
@@ -94,7 +96,7 @@ def gemm_nn(a: torch.Tensor, b: torch.Tensor, out=None, accumulate=False) -> tor
     elif out.stride(1) != 1 or tuple(out.shape) != (M, N):
         raise RuntimeError("gemm_nn: out must be (M, N) with contiguous rows")
     if M and N:
-        _run("sigma_gemm_nn_split3", _params(M, N, K, a, b, out, None, a.stride(0), b.stride(0), out.stride(0), accumulate), a.device)
+        _run("sigma_gemm_nn_split3", _params(M, N, K, a, b, out, None, a.stride(0), b.stride(0), out.stride(0), accumulate, pieces=pieces), a.device)
     return out
 
 
@@ -102,7 +104,7 @@ def tn_ok(a: torch.Tensor, b: torch.Tensor) -> bool:
     return a.shape[1] % 4 == 0 and b.shape[1] % 4 == 0 and _rows_ok(a) and _rows_ok(b)
 
 
-def gemm_tn(a: torch.Tensor, b: torch.Tensor, out=None, accumulate=False) -> torch.Tensor:
+def gemm_tn(a: torch.Tensor, b: torch.Tensor, out=None, accumulate=False, pieces: int = 2) -> torch.Tensor:
     """out (N, K) (+)= a (M, N)^T @ b (M, K): the reduction runs over the rows (tokens) of both operands"""
     _check2d(a, b)
     M, N = a.shape
@@ -117,11 +119,19 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, out=None, accumulate=False) -> tor
         out.zero_()
         accumulate = True
     if N and K:
-        _run("sigma_gemm_tn_split3", _params(M, N, K, a, b, out, None, a.stride(0), b.stride(0), out.stride(0), accumulate), a.device)
+        _run("sigma_gemm_tn_split3", _params(M, N, K, a, b, out, None, a.stride(0), b.stride(0), out.stride(0), accumulate, pieces=pieces), a.device)
     return out
 
 
-_WGRAD = os.environ.get("SIGMA_GEMM_WGRAD", "split3")      # "fp32": weight gradients stay on the vendor GEMM (A/B runs)
+def _pieces(var: str, default: str) -> int:
+    """per-GEMM-kind precision knob: '2' / '3' = bf16 pieces on the MFMA kernels, 'fp32' (-> 0) = vendor fp32 GEMM"""
+    v = os.environ.get(var, default)
+    return 0 if v == "fp32" else int(v)
+
+
+_FWD = _pieces("SIGMA_GEMM_FWD", "2")
+_DGRAD = _pieces("SIGMA_GEMM_DGRAD", "2")
+_WGRAD = _pieces("SIGMA_GEMM_WGRAD", "2")
 
 
 class LinearSplit3Fn(torch.autograd.Function):
@@ -130,7 +140,7 @@ class LinearSplit3Fn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x2, weight, bias):
-        y = gemm_nt(x2, weight, bias)
+        y = gemm_nt(x2, weight, bias, pieces=_FWD) if _FWD else nn.functional.linear(x2, weight, bias)
         ctx.save_for_backward(x2, weight)
         ctx.has_bias = bias is not None
         return y
@@ -141,9 +151,9 @@ class LinearSplit3Fn(torch.autograd.Function):
         g2 = dy if _rows_ok(dy) else dy.contiguous()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = gemm_nn(g2, weight) if nn_ok(g2, weight) else torch.mm(g2, weight)
+            dx = gemm_nn(g2, weight, pieces=_DGRAD) if (_DGRAD and nn_ok(g2, weight)) else torch.mm(g2, weight)
         if ctx.needs_input_grad[1]:
-            dw = gemm_tn(g2, x2) if (_WGRAD == "split3" and tn_ok(g2, x2)) else torch.mm(g2.t(), x2)
+            dw = gemm_tn(g2, x2, pieces=_WGRAD) if (_WGRAD and tn_ok(g2, x2)) else torch.mm(g2.t(), x2)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = g2.sum(0)
         return dx, dw, db

@@ -37,6 +37,8 @@ def main():
     a = ap.parse_args()
     rows = []
     dev = "cuda"
+    from sigma_amd.tuning import enable_tuned_gemms, tuned_gemms_active
+    enable_tuned_gemms()                      # the fp32 column = the tuned vendor GEMMs of the training step
     for name, M, K, N in SHAPES:
         if a.shapes and name not in a.shapes.split(","):
             continue
@@ -50,7 +52,9 @@ def main():
         ref = None
         if M * N <= 40e6:
             ref = x.double() @ w.double().t()
-        for label, fn in (("nt_split3", lambda: gemm.gemm_nt(x, w)), ("nt_fp32", lambda: torch.mm(x, w.t())),
+        for label, fn in (("nt_split3", lambda: gemm.gemm_nt(x, w)), ("nt_split6", lambda: gemm.gemm_nt(x, w, pieces=3)),
+                          ("nn_split6", lambda: gemm.gemm_nn(dy, w, pieces=3)), ("tn_split6", lambda: gemm.gemm_tn(dy, x, pieces=3)),
+                          ("nt_fp32", lambda: torch.mm(x, w.t())),
                           ("nn_split3", lambda: gemm.gemm_nn(dy, w)), ("nn_fp32", lambda: torch.mm(dy, w)),
                           ("tn_split3", lambda: gemm.gemm_tn(dy, x)), ("tn_fp32", lambda: torch.mm(dy.t(), x))):
             t = time_call(fn, a.iters)
@@ -59,11 +63,13 @@ def main():
             rec[label + "_hbm_frac"] = round(byts / t / 6.3e12, 3)
         if ref is not None:
             rec["nt_split3_err"] = float((gemm.gemm_nt(x, w).double() - ref).abs().max() / ref.abs().max())
+            rec["nt_split6_err"] = float((gemm.gemm_nt(x, w, pieces=3).double() - ref).abs().max() / ref.abs().max())
             rec["nt_fp32_err"] = float((torch.mm(x, w.t()).double() - ref).abs().max() / ref.abs().max())
         rows.append(rec)
         print(json.dumps(rec), flush=True)
         del x, w, dy, ref
         torch.cuda.empty_cache()
+    print(json.dumps(dict(tuned_gemms=tuned_gemms_active())), flush=True)
     if a.out:
         os.makedirs(os.path.dirname(os.path.abspath(a.out)) or ".", exist_ok=True)
         with open(a.out, "w") as f:
