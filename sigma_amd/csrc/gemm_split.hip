@@ -27,6 +27,12 @@
 #include "../../include/sigma_ops.h"
 #include "scan_device.h"
 
+// Ablation builds (-DSIGMA_GEMM_ABL=<bits>; WRONG results, timing only): 1 no MFMA / fragment reads, 2 no global operand
+// loads, 4 no C stores, 8 no fp32 -> bf16 split arithmetic (raw bits are stored), 16 no LDS stores and no barriers
+#ifndef SIGMA_GEMM_ABL
+#define SIGMA_GEMM_ABL 0
+#endif
+
 namespace sigma {
 namespace {
 
@@ -57,6 +63,11 @@ struct GemmArgs {
 // next residual: 8 significant bits each, round to nearest even (v_cvt_pk_bf16_f32)
 template <int P>
 __device__ __forceinline__ void split_pair(float x0, float x1, unsigned (&piece)[P]) {
+#if SIGMA_GEMM_ABL & 8
+#pragma unroll
+    for (int q = 0; q < P; ++q) piece[q] = __builtin_bit_cast(unsigned, q & 1 ? x1 : x0);
+    return;
+#endif
 #pragma unroll
     for (int q = 0; q < P; ++q) {
         const f32x2_t f = {x0, x1};
@@ -85,6 +96,12 @@ struct TileLoader {
     __device__ __forceinline__ void load(const float* __restrict__ src, long ld, long row0, long nrows, int k0, int kend) {
         const int t = threadIdx.x;
         const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+#if SIGMA_GEMM_ABL & 2
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = make_float4(0.5f + t, 0.25f, 1.0f + i, 2.0f);
+        asm volatile("" : "+v"(v[0].x));
+        return;
+#endif
         if constexpr (!KS) {
             const int kc = k0 + ((t & 7) << 2);
             const bool ok = FULL || kc < kend;                            // K % 4 == 0: a chunk is in or out as a whole
@@ -262,7 +279,12 @@ gemm_split3_kernel(const GemmArgs g) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const long row = rbase + (r & 3) + ((r >> 2) << 3);
-                    if (col_ok && row < g.M) put(it.Cb + row * g.ldc + col, acc[i][j][r] + bv);
+                    const float val = acc[i][j][r] + bv;
+#if SIGMA_GEMM_ABL & 4
+                    asm volatile("" :: "v"(val), "v"(row), "v"(col_ok));
+#else
+                    if (col_ok && row < g.M) put(it.Cb + row * g.ldc + col, val);
+#endif
                 }
             }
         }
@@ -272,12 +294,16 @@ gemm_split3_kernel(const GemmArgs g) {
 #pragma unroll
         for (int u = 0; u < kDepth; ++u) {
             if (!c_on) break;
+#if SIGMA_GEMM_ABL & 16
+            asm volatile("" :: "v"(la[u].v[0].x), "v"(lb_[u].v[0].x));
+#else
             la[u].template store<P>(sA, BM * kPitch);
             lb_[u].template store<P>(sB, BN * kPitch);
             __syncthreads();
+#endif
             produce(la[u], lb_[u]);                    // refill the slot just written to LDS: step s + kDepth
 #pragma unroll
-            for (int ks = 0; ks < kBK / 16; ++ks) {
+            for (int ks = 0; ks < (SIGMA_GEMM_ABL & 1 ? 0 : kBK / 16); ++ks) {
                 bf16x8_t fa[P][TM], fb[P][TN];
 #pragma unroll
                 for (int q = 0; q < P; ++q) {
@@ -298,7 +324,9 @@ gemm_split3_kernel(const GemmArgs g) {
                             for (int qa = sum; qa >= 0; --qa)
                                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[qa][i], fb[sum - qa][j], acc[i][j], 0, 0, 0);
             }
+#if !(SIGMA_GEMM_ABL & 16)
             __syncthreads();
+#endif
             ck += kBK;
             if (ck >= cit.kend) {                      // tile (slice) complete
                 if (g.mode == 0) epilogue(cit, [](float* dst, float v) { *dst = v; });

@@ -43,6 +43,13 @@ __device__ unsigned long long g_bwd4_prof[16];
 #define PROF_FLUSH
 #endif
 
+// Ablation builds (-DSIGMA_BWD4_ABL=<bits>; results are WRONG, timing only; profiles/r03_bwd4_ablation.txt):
+//   1 no du / ddelta stores   2 no dA / dD / ddelta_bias atomics   4 no column sums (barriers stay)
+//   8 no barriers and no column sums   16 no four-row folds / slab writes   32 no row prologue loads (constants)
+#ifndef SIGMA_BWD4_ABL
+#define SIGMA_BWD4_ABL 0
+#endif
+
 namespace sigma {
 
 #if SIGMA_BWD2_PROF
@@ -221,9 +228,15 @@ __device__ __forceinline__ void scan_bwd4_body(const BwdArgs& q, float* smem, in
             float dD_acc = 0.0f;                       // sum of dout * u over the lane's positions (zero past the end)
             {
                 float dv[T], uu[T];
+#if SIGMA_BWD4_ABL & 32
+#pragma unroll
+                for (int k = 0; k < T; ++k) { uu[k] = 0.5f + 0.01f * (lane + k); dv[k] = 0.1f * k; gg[k] = 1.0f - 0.02f * k; }
+                asm volatile("" : "+v"(uu[0]), "+v"(dv[0]), "+v"(gg[0]));
+#else
                 load_items<float, T, REV>(u_row, lbase, L, vec, uu);
                 load_items<float, T, REV>(d_row, lbase, L, vec, dv);
                 load_items<float, T, REV>(g_row, lbase, L, vec, gg);
+#endif
 #pragma unroll
                 for (int k = 0; k < T; ++k) {
                     float d = dv[k] + bias;
@@ -241,7 +254,9 @@ __device__ __forceinline__ void scan_bwd4_body(const BwdArgs& q, float* smem, in
             for (int k = 0; k < T; ++k) dsum += dl[k];
             // dA / dD / ddelta_bias leave through one atomicAdd per (row, tile) and state.  Summing them over the
             // tiles in LDS first (measured: WRITE_SIZE -6 %) costs the second B/C image its LDS and 3 % run time.
+#if !(SIGMA_BWD4_ABL & 2)
             if (kq->dD) { dD_acc = row_sum_to_lane0(dD_acc); if (li0) atomicAdd(kq->dD + pr, dD_acc); }
+#endif
 
             PROF(1)                                            // row prologue: loads, softplus
             // row scalars of state 0; those of state n + 1 are fetched while state n is computed
@@ -334,7 +349,11 @@ __device__ __forceinline__ void scan_bwd4_body(const BwdArgs& q, float* smem, in
                         vc[jj] = gg[k] * xs[k];                  // this row's term of dC[n, l]
                     }
                     // four-row sums: rows of the result = {dB pos 2qq, dB pos 2qq+1, dC pos 2qq, dC pos 2qq+1}
+#if SIGMA_BWD4_ABL & 16
+                    asm volatile("" :: "v"(vb[0]), "v"(vc[0]), "v"(vb[1]), "v"(vc[1]));
+#else
                     slab[2 * qq] = fold16(fold32(vb[0], vc[0]), fold32(vb[1], vc[1]));
+#endif
                 }
                 // collect: lane 0 of each row holds the result of this state; select + rotate, so that after
                 // N states the value of state n sits in lane 16 - N + n
@@ -342,7 +361,15 @@ __device__ __forceinline__ void scan_bwd4_body(const BwdArgs& q, float* smem, in
                 const float dA_row = row_sum_to_lane0(dAp);      // all lanes take part: outside the select
                 dA_v = row_rotate_left(li0 ? dA_row : dA_v);
                 PROF(5)                                        // reverse replay, four-row sums, slab writes, collect
+#if SIGMA_BWD4_ABL & 8
+                if (n == N - 1 && rb == RB - 1) {
+                    if (nbuf == 2) { lds_dma_wait(); __syncthreads(); }
+                    else { lds_barrier(); if (j > t_lo) stage(0, j - 1); }
+                }
+                if (false) {
+#else
                 if ((n % SB) == SB - 1) {
+#endif
                     // slabs of this state group complete; at the end of the tile also "next B/C image landed"
                     if (n == N - 1 && rb == RB - 1) {
                         if (nbuf == 2) { lds_dma_wait(); __syncthreads(); }
@@ -350,6 +377,10 @@ __device__ __forceinline__ void scan_bwd4_body(const BwdArgs& q, float* smem, in
                     } else {
                         lds_barrier();
                     }
+#if SIGMA_BWD4_ABL & 4
+                    ++grp;
+                    continue;
+#endif
                     PROF(6)                                    // barrier wait
                     const float* sset = sRed + ((grp & 1) * SB) * W * kCols4;
                     auto column = [&](int s, int c, int pos, bool is_c) {
@@ -398,7 +429,9 @@ __device__ __forceinline__ void scan_bwd4_body(const BwdArgs& q, float* smem, in
             if (li_e >= vshift) {
                 const int st = li_e - vshift;
                 sRv[rl_e * N + st] = rvout_v;
+#if !(SIGMA_BWD4_ABL & 2)
                 atomicAdd(ke->dA + (long)pr_e * ke->dA_ds + (long)st * ke->dA_ns, dA_v);
+#endif
             }
             float dbias_acc = 0.0f;
             float* __restrict__ du_row = reinterpret_cast<float*>(ke->du) + (long)b * ke->du_bs + (long)r_e * ke->du_ds;
@@ -429,9 +462,14 @@ __device__ __forceinline__ void scan_bwd4_body(const BwdArgs& q, float* smem, in
 #pragma unroll
                     for (int qq = 0; qq < T / 2; ++qq) {
                         const int k = 2 * qq;
-                        store_pair<REV>(du_row, lbase_e, L, vec, qq, fmaf(Dd, gg[k], dl[k] * sdxB[k]), fmaf(Dd, gg[k + 1], dl[k + 1] * sdxB[k + 1]));
+                        const float u0 = fmaf(Dd, gg[k], dl[k] * sdxB[k]), u1 = fmaf(Dd, gg[k + 1], dl[k + 1] * sdxB[k + 1]);
                         const float d0 = dd_of(k), d1 = dd_of(k + 1);
+#if SIGMA_BWD4_ABL & 1
+                        asm volatile("" :: "v"(u0), "v"(u1), "v"(d0), "v"(d1));
+#else
+                        store_pair<REV>(du_row, lbase_e, L, vec, qq, u0, u1);
                         store_pair<REV>(dd_row, lbase_e, L, vec, qq, d0, d1);
+#endif
                         dbias_acc += d0 + d1;          // zero past the end (dl = 0 there)
                     }
                 } else {
@@ -450,7 +488,11 @@ __device__ __forceinline__ void scan_bwd4_body(const BwdArgs& q, float* smem, in
                     }
                 }
             }
+#if !(SIGMA_BWD4_ABL & 2)
             if (ke->dbias) { dbias_acc = row_sum_to_lane0(dbias_acc); if (li_e == 0) atomicAdd(ke->dbias + pr_e, dbias_acc); }
+#else
+            asm volatile("" :: "v"(dbias_acc), "v"(dA_v));
+#endif
             PROF(8)                                            // row epilogue
         }
         if (nbuf == 2) buf ^= 1;

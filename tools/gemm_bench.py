@@ -34,6 +34,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--out", default="")
     ap.add_argument("--shapes", default="")
+    ap.add_argument("--only", default="", help="comma separated column labels (e.g. nt_split3,tn_split3); default all")
     a = ap.parse_args()
     rows = []
     dev = "cuda"
@@ -57,11 +58,13 @@ def main():
                           ("nt_fp32", lambda: torch.mm(x, w.t())),
                           ("nn_split3", lambda: gemm.gemm_nn(dy, w)), ("nn_fp32", lambda: torch.mm(dy, w)),
                           ("tn_split3", lambda: gemm.gemm_tn(dy, x)), ("tn_fp32", lambda: torch.mm(dy.t(), x))):
+            if a.only and label not in a.only.split(","):
+                continue
             t = time_call(fn, a.iters)
             rec[label + "_us"] = round(t * 1e6, 1)
             rec[label + "_TF"] = round(flops / t / 1e12, 1)
             rec[label + "_hbm_frac"] = round(byts / t / 6.3e12, 3)
-        if ref is not None:
+        if ref is not None and not a.only:
             rec["nt_split3_err"] = float((gemm.gemm_nt(x, w).double() - ref).abs().max() / ref.abs().max())
             rec["nt_split6_err"] = float((gemm.gemm_nt(x, w, pieces=3).double() - ref).abs().max() / ref.abs().max())
             rec["nt_fp32_err"] = float((torch.mm(x, w.t()).double() - ref).abs().max() / ref.abs().max())

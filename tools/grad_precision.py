@@ -47,8 +47,16 @@ def run(case, fwd, dgrad, wgrad):
 
 
 def main():
+    settings = SETTINGS
+    if len(sys.argv) > 1:            # e.g. f3_d2_w2 f3_d3_w3 f3_d3_w3
+        def parse(tok):
+            if tok == "fp32":
+                return ("fp32", 0, 0, 0)
+            parts = dict((p[0], int(p[1:])) for p in tok.split("_"))
+            return (tok, parts.get("f", 0), parts.get("d", 0), parts.get("w", 0))
+        settings = [parse(t) for t in sys.argv[1:]]
     for case in ("tiny_64x96", "tiny_72x88_b2"):
-        for name, f, d, w in SETTINGS:
+        for name, f, d, w in settings:
             rec = dict(case=case, setting=name, **run(case, f, d, w))
             print(json.dumps(rec), flush=True)
 
