@@ -250,9 +250,10 @@ def main():
     finally:
         os.chdir(cwd)
     model.to(dev).train()
-    use_graph = bool(a.graph) and not ddp
+    use_graph = bool(a.graph)
     opt = ts.make_optimizer(model, capturable=use_graph)
-    net = ts.wrap_ddp(model, dev)           # train.py:107
+    # train.py:107; under --graph the data-parallel step is two HIP graphs around one flat RCCL all-reduce
+    net = model if (use_graph and ddp) else ts.wrap_ddp(model, dev)
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     rgb = torch.randn(a.batch, 3, a.height, a.width, generator=g).to(dev)
     mx = torch.randn(a.batch, 3, a.height, a.width, generator=g).to(dev)
@@ -271,7 +272,10 @@ def main():
         timer.enabled = False
         eager_scan_steps = 2
         core.set_launch_hook(None)
-        gstep, _ = ts.make_graphed_step(net, opt, (rgb, mx, label))
+        if ddp:
+            gstep, _ = ts.make_graphed_ddp_step(model, opt, (rgb, mx, label), bf16_comm=os.environ.get("SIGMA_DDP_BF16", "0") == "1")
+        else:
+            gstep, _ = ts.make_graphed_step(net, opt, (rgb, mx, label))
         elapsed, loss = ts.timed_steps(gstep, a.steps, a.warmup, dev)
     else:
         # the timed region runs WITHOUT the per-launch HIP events (two events around each of ~270 scan launches per step

@@ -80,99 +80,115 @@ __device__ __forceinline__ void split_pair(float x0, float x1, unsigned (&piece)
     }
 }
 
-// ---- operand tile loaders: ROWS rows (output index) x 32 k, into registers, then split into the LDS images ----
+// ---- operand tile loaders: ROWS rows (output index) x 32 k ------------------------------------------------------------
 // KS = false: memory [row][k] (k contiguous).  thread t: k-chunk t & 7 (4 floats), rows (t >> 3) + 32 i.
-// KS = true : memory [k][row] (row contiguous).  thread t: k-group t & 7 (k = 4 (t & 7) + j), row chunk (t >> 3) (+ 32 i).
+// KS = true : memory [k][row] (row contiguous).  thread t: k = 4 (t & 7) + j, row chunk (t >> 3) (+ 32 i): four k-rows of
+//             the same four rows, packed along k on the way into LDS (the transposition).
+// A load is global_load_dwordx4 vdst, voffset, s[base]: the per-thread 32-bit byte offsets depend only on the thread and
+// on the tile's row clamp (recomputed when the workgroup moves to another tile), the 64-bit base is wave-uniform and
+// moves with the k-step.  The loads are issued from inline asm, so hipcc does not know them: with loads of its own it
+// drains vmcnt(0) at every loop-carried use (measured: operands 1, 2 or 3 steps ahead ran at the same speed,
+// profiles/r03_gemm_depth.txt); the kernel counts them itself (LPS loads per stage, s_waitcnt vmcnt(newer * LPS)).
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
 template <int ROWS, bool KS>
 struct TileLoader {
-    static constexpr int NV = KS ? ((ROWS + 127) / 128) * 4 : ROWS / 32;    // float4 registers per thread
-    float4 v[NV];
+    static constexpr int NV = KS ? ((ROWS + 127) / 128) * 4 : ROWS / 32;    // 16-byte loads per thread and stage
+    unsigned off[NV];
 
-    // src: first element of the operand (batch applied); row0: first row of the tile; nrows: valid rows of the operand;
-    // k0: first reduction index of this step; kend: end of the reduction range.  FULL: the whole k-step is in range
-    // (wave-uniform, the common case); otherwise out-of-range k are loaded from a clamped address and zeroed.  Every load
-    // is unconditional (a per-lane "load or zero" makes hipcc branch around each load).
-    template <bool FULL>
-    __device__ __forceinline__ void load(const float* __restrict__ src, long ld, long row0, long nrows, int k0, int kend) {
+    // row0: first row of the tile, nrows: rows of the operand (tail rows repeat the last valid row / chunk: their
+    // products are masked at the C store)
+    __device__ __forceinline__ void set_tile(long ld, long row0, long nrows) {
         const int t = threadIdx.x;
-        const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
-#if SIGMA_GEMM_ABL & 2
-#pragma unroll
-        for (int i = 0; i < NV; ++i) v[i] = make_float4(0.5f + t, 0.25f, 1.0f + i, 2.0f);
-        asm volatile("" : "+v"(v[0].x));
-        return;
-#endif
         if constexpr (!KS) {
-            const int kc = k0 + ((t & 7) << 2);
-            const bool ok = FULL || kc < kend;                            // K % 4 == 0: a chunk is in or out as a whole
-            const int kl = ok ? kc : kend - 4;
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
                 long row = row0 + (t >> 3) + 32 * i;
-                row = row < nrows ? row : nrows - 1;                      // tail rows: duplicates, masked at the C store
-                const float4 x = *reinterpret_cast<const float4*>(src + row * ld + kl);
-                v[i] = ok ? x : zero;
+                row = row < nrows ? row : nrows - 1;
+                off[i] = (unsigned)(((row - row0) * ld + ((t & 7) << 2)) * 4);
             }
         } else {
-            const int kg = k0 + ((t & 7) << 2);
 #pragma unroll
             for (int i = 0; i < NV / 4; ++i) {
-                int ch = (t >> 3) + 32 * i;                               // chunk of 4 rows inside the tile
+                int ch = (t >> 3) + 32 * i;
                 ch = ch < ROWS / 4 ? ch : ROWS / 4 - 1;                   // lanes past the tile repeat its last chunk
                 long row = row0 + 4L * ch;
-                row = row + 4 <= nrows ? row : nrows - 4;                 // nrows % 4 == 0 (host-checked)
+                row = row + 4 <= nrows ? row : nrows - 4;                 // nrows % 4 == 0, row0 % 4 == 0 (host-checked)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const bool ok = FULL || kg + j < kend;
-                    const int kl = ok ? kg + j : kend - 1;
-                    const float4 x = *reinterpret_cast<const float4*>(src + (long)kl * ld + row);
-                    v[4 * i + j] = ok ? x : zero;
-                }
+                for (int j = 0; j < 4; ++j) off[4 * i + j] = (unsigned)(((long)(((t & 7) << 2) + j) * ld + (row - row0)) * 4);
             }
         }
     }
 
-    // split into P bf16 images [row][k], image q at img + q * img_stride
+    // base: element (row0, k0) of the operand; rem = reduction elements left from k0 (>= 32: a full step)
+    __device__ __forceinline__ void issue(f32x4_t (&v)[NV], const float* base, int rem, long ld) const {
+        const int t = threadIdx.x;
+#if SIGMA_GEMM_ABL & 2
+#pragma unroll
+        for (int i = 0; i < NV; ++i) { v[i] = f32x4_t{0.5f + t, 0.25f, 1.0f + i, 2.0f}; asm volatile("" : "+v"(v[i])); }
+        return;
+#endif
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            unsigned o = off[i];
+            if (rem < kBK) {                                              // wave-uniform: the last, partial k-step
+                if constexpr (!KS) {
+                    const int kc = (t & 7) << 2;
+                    if (kc >= rem) o -= (unsigned)(kc - (rem - 4)) * 4u;            // K % 4 == 0: re-read the last chunk
+                } else {
+                    const int kk = ((t & 7) << 2) + (i & 3);
+                    if (kk >= rem) o -= (unsigned)((long)(kk - (rem - 1)) * ld * 4);
+                }
+            }
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v[i]) : "v"(o), "s"(base) : "memory");
+        }
+    }
+
+    // split into P bf16 images [row][k], image q at img + q * img_stride; elements past the reduction range are zero
     template <int P>
-    __device__ __forceinline__ void store(uint16_t* __restrict__ img, int img_stride) const {
+    __device__ __forceinline__ void store(const f32x4_t (&v)[NV], int rem, uint16_t* __restrict__ img, int img_stride) const {
         const int t = threadIdx.x;
         if constexpr (!KS) {
+            const bool ok = ((t & 7) << 2) < rem;
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
-                const int off = ((t >> 3) + 32 * i) * kPitch + ((t & 7) << 2);
+                const int o = ((t >> 3) + 32 * i) * kPitch + ((t & 7) << 2);
+                const f32x4_t x = ok ? v[i] : f32x4_t{0.f, 0.f, 0.f, 0.f};
                 unsigned p01[P], p23[P];
-                split_pair<P>(v[i].x, v[i].y, p01);
-                split_pair<P>(v[i].z, v[i].w, p23);
+                split_pair<P>(x[0], x[1], p01);
+                split_pair<P>(x[2], x[3], p23);
 #pragma unroll
-                for (int q = 0; q < P; ++q) *reinterpret_cast<uint2*>(img + q * img_stride + off) = make_uint2(p01[q], p23[q]);
+                for (int q = 0; q < P; ++q) *reinterpret_cast<uint2*>(img + q * img_stride + o) = make_uint2(p01[q], p23[q]);
             }
         } else {
 #pragma unroll
             for (int i = 0; i < NV / 4; ++i) {
                 int ch = (t >> 3) + 32 * i;
                 ch = ch < ROWS / 4 ? ch : ROWS / 4 - 1;                   // repeated chunk: same values, same address
-                const float* f0 = reinterpret_cast<const float*>(&v[4 * i + 0]);
-                const float* f1 = reinterpret_cast<const float*>(&v[4 * i + 1]);
-                const float* f2 = reinterpret_cast<const float*>(&v[4 * i + 2]);
-                const float* f3 = reinterpret_cast<const float*>(&v[4 * i + 3]);
+                f32x4_t x[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) x[j] = (((t & 7) << 2) + j < rem) ? v[4 * i + j] : f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int off = (4 * ch + r) * kPitch + ((t & 7) << 2);
+                    const int o = (4 * ch + r) * kPitch + ((t & 7) << 2);
                     unsigned p01[P], p23[P];
-                    split_pair<P>(f0[r], f1[r], p01);
-                    split_pair<P>(f2[r], f3[r], p23);
+                    split_pair<P>(x[0][r], x[1][r], p01);
+                    split_pair<P>(x[2][r], x[3][r], p23);
 #pragma unroll
-                    for (int q = 0; q < P; ++q) *reinterpret_cast<uint2*>(img + q * img_stride + off) = make_uint2(p01[q], p23[q]);
+                    for (int q = 0; q < P; ++q) *reinterpret_cast<uint2*>(img + q * img_stride + o) = make_uint2(p01[q], p23[q]);
                 }
             }
         }
     }
 };
 
+template <int N>
+__device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
+
 #ifndef SIGMA_GEMM_DEPTH
 #define SIGMA_GEMM_DEPTH 2
 #endif
-constexpr int kDepth = SIGMA_GEMM_DEPTH;   // k-steps of operands in flight per workgroup (register ring; 3 spills at 128 x 128)
+constexpr int kDepth = SIGMA_GEMM_DEPTH;   // k-steps of operands in flight per workgroup (register ring)
 
 // one output tile (x one reduction slice) of one problem of the batch
 struct Item {
@@ -183,9 +199,8 @@ struct Item {
 // Persistent workgroups: workgroup b walks the work items b, b + gridDim.x, ... (an item = one BM x BN output tile
 // x one reduction slice); its k-steps form ONE stream that crosses item boundaries, and the operands of step s + kDepth
 // are requested from global memory when step s is consumed -- HBM latency (~2 us under load, i.e. several k-steps of
-// MFMA time) is covered by the ring instead of by occupancy (174 registers: two workgroups per CU), and the epilogue
-// of a tile overlaps the first loads of the next one.  Measured against the first version (operands one step ahead,
-// one tile per workgroup): see profiles/r03_gemm_bench.jsonl.
+// MFMA time) is covered by the ring instead of by occupancy (two workgroups per CU), and the epilogue of a tile
+// overlaps the first loads of the next one.
 template <int BM, int BN, int WM, int WN, bool A_KS, bool B_KS, int P>
 __global__ void __launch_bounds__(256, 2)
 gemm_split3_kernel(const GemmArgs g) {
@@ -193,9 +208,14 @@ gemm_split3_kernel(const GemmArgs g) {
     constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
     static_assert(TM >= 1 && TN >= 1 && TM * 32 * WM == BM && TN * 32 * WN == BN, "tile shape");
     static_assert(P == 2 || P == 3, "two or three bf16 pieces per operand");
+    static_assert(kDepth >= 1 && kDepth <= 3, "ring depth");
     __shared__ __attribute__((aligned(16))) uint16_t smem[P * (BM + BN) * kPitch];
     uint16_t* sA = smem;                               // [P][BM][kPitch]
     uint16_t* sB = smem + P * BM * kPitch;             // [P][BN][kPitch]
+    typedef TileLoader<BM, A_KS> LoaderA;
+    typedef TileLoader<BN, B_KS> LoaderB;
+    constexpr int LPS = LoaderA::NV + LoaderB::NV;     // loads per thread and stage
+    static_assert((kDepth - 1) * LPS <= 63, "vmcnt is 6 bits");
 
     const int per_z = g.ntm * g.ntn * g.slices;
     const int total = g.batch * per_z;
@@ -227,28 +247,38 @@ gemm_split3_kernel(const GemmArgs g) {
     bool p_on = p_id < total, c_on = p_on;
     Item pit, cit;
     int pk = 0, ck = 0;
-    if (p_on) { decode(p_id, pit); cit = pit; pk = pit.kbeg; ck = pk; }
+    LoaderA la;
+    LoaderB lb_;
+    if (p_on) {
+        decode(p_id, pit); cit = pit; pk = pit.kbeg; ck = pk;
+        la.set_tile(g.lda, pit.m0, g.M);
+        lb_.set_tile(g.ldb, pit.n0, g.N);
+    }
 
-    TileLoader<BM, A_KS> la[kDepth];
-    TileLoader<BN, B_KS> lb_[kDepth];
-    auto produce = [&](TileLoader<BM, A_KS>& LA, TileLoader<BN, B_KS>& LB) {
+    f32x4_t va[kDepth][LoaderA::NV], vb[kDepth][LoaderB::NV];     // the ring
+    int rem_[kDepth];                                              // reduction elements of the stage in slot d (0: empty)
+    auto produce = [&](int d_, f32x4_t (&VA)[LoaderA::NV], f32x4_t (&VB)[LoaderB::NV]) {
+        rem_[d_] = 0;
         if (!p_on) return;
-        if (pk + kBK <= pit.kend) {
-            LA.template load<true>(pit.Ab, g.lda, pit.m0, g.M, pk, pit.kend);
-            LB.template load<true>(pit.Bb, g.ldb, pit.n0, g.N, pk, pit.kend);
-        } else {
-            LA.template load<false>(pit.Ab, g.lda, pit.m0, g.M, pk, pit.kend);
-            LB.template load<false>(pit.Bb, g.ldb, pit.n0, g.N, pk, pit.kend);
-        }
+        const int rem = pit.kend - pk;
+        const float* abase = pit.Ab + (A_KS ? (long)pk * g.lda + pit.m0 : pit.m0 * g.lda + pk);
+        const float* bbase = pit.Bb + (B_KS ? (long)pk * g.ldb + pit.n0 : (long)pit.n0 * g.ldb + pk);
+        la.issue(VA, abase, rem, g.lda);
+        lb_.issue(VB, bbase, rem, g.ldb);
+        rem_[d_] = rem < kBK ? rem : kBK;
         pk += kBK;
         if (pk >= pit.kend) {
             p_id += gridDim.x;
             p_on = p_id < total;
-            if (p_on) { decode(p_id, pit); pk = pit.kbeg; }
+            if (p_on) {
+                decode(p_id, pit); pk = pit.kbeg;
+                la.set_tile(g.lda, pit.m0, g.M);
+                lb_.set_tile(g.ldb, pit.n0, g.N);
+            }
         }
     };
 #pragma unroll
-    for (int d = 0; d < kDepth; ++d) produce(la[d], lb_[d]);
+    for (int d = 0; d < kDepth; ++d) produce(d, va[d], vb[d]);
 
     f32x16_t acc[TM][TN];
     auto zero_acc = [&]() {
@@ -266,24 +296,43 @@ gemm_split3_kernel(const GemmArgs g) {
     const uint16_t* fA = sA + (wm * TM * 32) * kPitch + frag;
     const uint16_t* fB = sB + (wn * TN * 32) * kPitch + frag;
 
-    // epilogue: C/D layout of the 32x32 MFMA: register r of lane l = row (r & 3) + 8 (r >> 2) + 4 (l >> 5), col l & 31
+    // epilogue: C/D layout of the 32x32 MFMA: register r of lane l = row (r & 3) + 8 (r >> 2) + 4 (l >> 5), col l & 31.
+    // No compiler-visible load may be pending while the stores are issued: with one (the bias) hipcc put
+    // s_waitcnt vmcnt(0) in front of every element's store -- stores count in vmcnt on gfx9, so each of the 64 stores
+    // of a thread waited for the previous one to reach L2 (the epilogue was 29 % of the kernel,
+    // profiles/r03_gemm_ablation.txt).  The bias is therefore fetched first, waited for explicitly and laundered; tiles
+    // that lie inside the matrix store without per-element bounds branches.
     auto epilogue = [&](const Item& it, auto put) {
+        float bv[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bv[j] = 0.0f;
+        if (g.bias != nullptr && it.sl == 0) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = it.n0 + (wn * TN + j) * 32 + (lane & 31);
+                bv[j] = g.bias[col < g.N ? col : g.N - 1];
+            }
+            vm_wait<0>();
+#pragma unroll
+            for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(bv[j]));
+        }
+        const bool inside = it.m0 + BM <= g.M && it.n0 + BN <= g.N;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int col = it.n0 + (wn * TN + j) * 32 + (lane & 31);
-            const bool col_ok = col < g.N;
-            const float bv = (g.bias != nullptr && col_ok && it.sl == 0) ? g.bias[col] : 0.0f;
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const long rbase = it.m0 + (wm * TM + i) * 32 + ((lane >> 5) << 2);
+                float* __restrict__ p0 = it.Cb + rbase * g.ldc + col;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const long row = rbase + (r & 3) + ((r >> 2) << 3);
-                    const float val = acc[i][j][r] + bv;
+                    const int dr = (r & 3) + ((r >> 2) << 3);
+                    const float val = acc[i][j][r] + bv[j];
 #if SIGMA_GEMM_ABL & 4
-                    asm volatile("" :: "v"(val), "v"(row), "v"(col_ok));
+                    asm volatile("" :: "v"(val), "v"(p0));
 #else
-                    if (col_ok && row < g.M) put(it.Cb + row * g.ldc + col, val);
+                    if (inside) put(p0 + (long)dr * g.ldc, val);
+                    else if (col < g.N && rbase + dr < g.M) put(p0 + (long)dr * g.ldc, val);
 #endif
                 }
             }
@@ -294,14 +343,28 @@ gemm_split3_kernel(const GemmArgs g) {
 #pragma unroll
         for (int u = 0; u < kDepth; ++u) {
             if (!c_on) break;
+            // the loads of slot u are complete when at most the loads of the NEWER stages are outstanding (in-order return)
+            {
+                int newer = 0;
+#pragma unroll
+                for (int d = 0; d < kDepth; ++d) if (d != u && rem_[d] > 0) ++newer;
+                if (kDepth >= 3 && newer >= 2) vm_wait<2 * LPS>();
+                else if (kDepth >= 2 && newer == 1) vm_wait<LPS>();
+                else vm_wait<0>();
+#pragma unroll
+                for (int i = 0; i < LoaderA::NV; ++i) asm volatile("" : "+v"(va[u][i]));      // uses stay behind the wait
+#pragma unroll
+                for (int i = 0; i < LoaderB::NV; ++i) asm volatile("" : "+v"(vb[u][i]));
+            }
+            const int rem_u = rem_[u];
 #if SIGMA_GEMM_ABL & 16
-            asm volatile("" :: "v"(la[u].v[0].x), "v"(lb_[u].v[0].x));
+            asm volatile("" :: "v"(va[u][0]), "v"(vb[u][0]));
 #else
-            la[u].template store<P>(sA, BM * kPitch);
-            lb_[u].template store<P>(sB, BN * kPitch);
-            __syncthreads();
+            la.template store<P>(va[u], rem_u, sA, BM * kPitch);
+            lb_.template store<P>(vb[u], rem_u, sB, BN * kPitch);
+            lds_barrier();
 #endif
-            produce(la[u], lb_[u]);                    // refill the slot just written to LDS: step s + kDepth
+            produce(u, va[u], vb[u]);                  // refill the slot just written to LDS: step s + kDepth
 #pragma unroll
             for (int ks = 0; ks < (SIGMA_GEMM_ABL & 1 ? 0 : kBK / 16); ++ks) {
                 bf16x8_t fa[P][TM], fb[P][TN];
@@ -325,7 +388,7 @@ gemm_split3_kernel(const GemmArgs g) {
                                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[qa][i], fb[sum - qa][j], acc[i][j], 0, 0, 0);
             }
 #if !(SIGMA_GEMM_ABL & 16)
-            __syncthreads();
+            lds_barrier();
 #endif
             ck += kBK;
             if (ck >= cit.kend) {                      // tile (slice) complete

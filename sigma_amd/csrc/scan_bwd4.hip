@@ -233,9 +233,9 @@ __device__ __forceinline__ void scan_bwd4_body(const BwdArgs& q, float* smem, in
                 for (int k = 0; k < T; ++k) { uu[k] = 0.5f + 0.01f * (lane + k); dv[k] = 0.1f * k; gg[k] = 1.0f - 0.02f * k; }
                 asm volatile("" : "+v"(uu[0]), "+v"(dv[0]), "+v"(gg[0]));
 #else
-                load_items<float, T, REV>(u_row, lbase, L, vec, uu);
-                load_items<float, T, REV>(d_row, lbase, L, vec, dv);
-                load_items<float, T, REV>(g_row, lbase, L, vec, gg);
+                load10<REV>(u_row, lbase, L, vec, uu);
+                load10<REV>(d_row, lbase, L, vec, dv);
+                load10<REV>(g_row, lbase, L, vec, gg);
 #endif
 #pragma unroll
                 for (int k = 0; k < T; ++k) {
@@ -459,33 +459,35 @@ __device__ __forceinline__ void scan_bwd4_body(const BwdArgs& q, float* smem, in
                         const float sig = d > 0.25f ? big : ser * d;
                         return live ? (usx + sAx[k]) * sig : 0.0f;
                     };
+                    float duv[T], ddv[T];
 #pragma unroll
-                    for (int qq = 0; qq < T / 2; ++qq) {
-                        const int k = 2 * qq;
-                        const float u0 = fmaf(Dd, gg[k], dl[k] * sdxB[k]), u1 = fmaf(Dd, gg[k + 1], dl[k + 1] * sdxB[k + 1]);
-                        const float d0 = dd_of(k), d1 = dd_of(k + 1);
-#if SIGMA_BWD4_ABL & 1
-                        asm volatile("" :: "v"(u0), "v"(u1), "v"(d0), "v"(d1));
-#else
-                        store_pair<REV>(du_row, lbase_e, L, vec, qq, u0, u1);
-                        store_pair<REV>(dd_row, lbase_e, L, vec, qq, d0, d1);
-#endif
-                        dbias_acc += d0 + d1;          // zero past the end (dl = 0 there)
+                    for (int k = 0; k < T; ++k) {
+                        duv[k] = fmaf(Dd, gg[k], dl[k] * sdxB[k]);
+                        ddv[k] = dd_of(k);
+                        dbias_acc += ddv[k];           // zero past the end (dl = 0 there)
                     }
+#if SIGMA_BWD4_ABL & 1
+#pragma unroll
+                    for (int k = 0; k < T; ++k) asm volatile("" :: "v"(duv[k]), "v"(ddv[k]));
+#else
+                    store10<REV>(du_row, lbase_e, L, vec, duv);
+                    store10<REV>(dd_row, lbase_e, L, vec, ddv);
+#endif
                 } else {
                     const int rpg2 = ke->f.rows_per_group;
                     const int ur2 = r_e - ((g - (g >> ke->f.u_gshift)) * rpg2);
                     const float* __restrict__ u_row2 = reinterpret_cast<const float*>(ke->f.u) + (long)b * ke->f.u_bs + (long)ur2 * ke->f.u_ds;
                     float uu[T];
-                    load_items<float, T, REV>(u_row2, lbase_e, L, vec, uu);
+                    load10<REV>(u_row2, lbase_e, L, vec, uu);
+                    float duv[T], ddv[T];
 #pragma unroll
-                    for (int qq = 0; qq < T / 2; ++qq) {
-                        const int k = 2 * qq;
-                        store_pair<REV>(du_row, lbase_e, L, vec, qq, fmaf(Dd, gg[k], dl[k] * sdxB[k]), fmaf(Dd, gg[k + 1], dl[k + 1] * sdxB[k + 1]));
-                        const float d0 = fmaf(uu[k], sdxB[k], sAx[k]), d1 = fmaf(uu[k + 1], sdxB[k + 1], sAx[k + 1]);
-                        store_pair<REV>(dd_row, lbase_e, L, vec, qq, d0, d1);
-                        dbias_acc += ((lbase_e + k < L) ? d0 : 0.0f) + ((lbase_e + k + 1 < L) ? d1 : 0.0f);
+                    for (int k = 0; k < T; ++k) {
+                        duv[k] = fmaf(Dd, gg[k], dl[k] * sdxB[k]);
+                        ddv[k] = fmaf(uu[k], sdxB[k], sAx[k]);
+                        dbias_acc += (lbase_e + k < L) ? ddv[k] : 0.0f;
                     }
+                    store10<REV>(du_row, lbase_e, L, vec, duv);
+                    store10<REV>(dd_row, lbase_e, L, vec, ddv);
                 }
             }
 #if !(SIGMA_BWD4_ABL & 2)

@@ -50,6 +50,25 @@ def test_gemm_nt_against_fp64(shape, with_bias):
     _assert_close(got, want, _bound(a.double(), w.double().t()), "nt")
 
 
+@pytest.mark.parametrize("shape", [(19200, 384, 1536), (300, 768, 1536), (18, 768, 1536), (18, 1536, 768), (6, 768, 1536), (792, 96, 384),
+                                   (257, 100, 70), (5, 4, 3)], ids=lambda s: "x".join(map(str, s)))
+def test_three_piece_gemms_reach_fp32_accuracy(shape):
+    """pieces = 3 (hi, mid, lo: six MFMAs per block): error against fp64 at the level of an fp32 GEMM (~1e-6 of
+    sum |a||b|), for the forward (nt), the input gradient (nn) and the weight gradient (tn)."""
+    from sigma_amd import gemm
+    M, K, N = shape
+    a, w = _rand(M, K, seed=21), _rand(N, K, seed=22, scale=0.05)
+    bias = _rand(N, seed=23)
+    def check(got, want, bound, what):
+        worst = float(((got.double() - want).abs() / (bound + 1e-30)).max())
+        assert worst < 2e-6, f"{what}: max error / sum|a||b| = {worst:.3e}"
+    check(gemm.gemm_nt(a, w, bias, pieces=3), a.double() @ w.double().t() + bias.double(), _bound(a.double(), w.double().t()), "nt p3")
+    if N % 4 == 0 and K % 4 == 0:
+        dy = _rand(M, N, seed=24)
+        check(gemm.gemm_nn(dy, w, pieces=3), dy.double() @ w.double(), _bound(dy.double(), w.double()), "nn p3")
+        check(gemm.gemm_tn(dy, a, pieces=3), dy.double().t() @ a.double(), _bound(dy.double().t(), a.double()), "tn p3")
+
+
 def test_gemm_nt_is_not_transposed_identity_check():
     """A = I with an ASYMMETRIC B: catches a row/column swap in the accumulator write (a symmetric B would not)."""
     from sigma_amd import gemm

@@ -32,10 +32,13 @@ def run(case, fwd, dgrad, wgrad):
     loss = model(rgb.cuda(), x.cuda(), label.cuda())
     loss.backward()
     got = dict(model.named_parameters())
-    worst_d = 0.0
+    worst_d, dlist = 0.0, []
     for n, r in zip(list(z["grad_names"]), z["grad_digest"]):
         d = digest(got[n].grad)
-        worst_d = max(worst_d, max(abs(float(d[i]) - float(r[i])) for i in range(3)) / (abs(float(r[1])) + 1e-6))
+        e = max(abs(float(d[i]) - float(r[i])) for i in range(3)) / (abs(float(r[1])) + 1e-6)
+        dlist.append((e, str(n)))
+        worst_d = max(worst_d, e)
+    dlist.sort(reverse=True)
     worst_e, worst_n = 0.0, ""
     for i, n in enumerate(list(z["grad_full_names"])):
         r = torch.from_numpy(z[f"grad_full_{i}"])
@@ -43,7 +46,7 @@ def run(case, fwd, dgrad, wgrad):
         e = float((g - r).abs().max()) / (float(r.abs().max()) + 1e-7)
         if e > worst_e:
             worst_e, worst_n = e, str(n)
-    return dict(logit_err=logit_err, loss_err=abs(loss.item() - float(z["loss"])), worst_digest=worst_d, worst_elem=worst_e, worst_elem_name=worst_n)
+    return dict(top_digest=[(round(e, 6), n) for e, n in dlist[:4]], logit_err=logit_err, loss_err=abs(loss.item() - float(z["loss"])), worst_digest=worst_d, worst_elem=worst_e, worst_elem_name=worst_n)
 
 
 def main():
