@@ -93,6 +93,15 @@ int sigma_transpose2d(const sigma_transpose_params *params, void *stream);
  *       vmamba.py:91-98); replaces two strided torch adds.                                        */
 int sigma_pair_sum_add(const float *src, float *acc, int64_t n_outer, int64_t inner, void *stream);
 
+/*   sigma_upsample2x_nhwc
+ *       F.interpolate(scale_factor=2, mode="bilinear", align_corners=False) of a contiguous channels-last fp32 tensor
+ *       (B, H, W, C) -> (B, 2H, 2W, C) (backward = 0), and its adjoint (backward = 1: `in` is the gradient
+ *       (B, 2H, 2W, C), `out` the input gradient (B, H, W, C); height / width are ALWAYS those of the small tensor):
+ *       the decoder's UpsampleExpand / FinalUpsample_X4 (models/decoders/MambaDecoder.py:33-51, 76-97).  C % 4 == 0,
+ *       16-byte aligned pointers.  Gather formulation in both directions (deterministic, no atomics).           */
+int sigma_upsample2x_nhwc(const float *in, float *out, int32_t batch, int32_t height, int32_t width, int32_t channels,
+                          int32_t backward, void *stream);
+
 /*   sigma_split_bf16
  *       Operand images of the split-operand bf16 GEMM (sigma_amd/split_linear.py; the nn.Linear calls of
  *       vmamba.py, e.g. SS2D.in_proj / out_proj :1067-1089): with hi = bf16(x) and lo = bf16(x - hi), row r of the

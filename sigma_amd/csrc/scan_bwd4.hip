@@ -233,9 +233,9 @@ __device__ __forceinline__ void scan_bwd4_body(const BwdArgs& q, float* smem, in
                 for (int k = 0; k < T; ++k) { uu[k] = 0.5f + 0.01f * (lane + k); dv[k] = 0.1f * k; gg[k] = 1.0f - 0.02f * k; }
                 asm volatile("" : "+v"(uu[0]), "+v"(dv[0]), "+v"(gg[0]));
 #else
-                load10<REV>(u_row, lbase, L, vec, uu);
-                load10<REV>(d_row, lbase, L, vec, dv);
-                load10<REV>(g_row, lbase, L, vec, gg);
+                load_items<float, T, REV>(u_row, lbase, L, vec, uu);
+                load_items<float, T, REV>(d_row, lbase, L, vec, dv);
+                load_items<float, T, REV>(g_row, lbase, L, vec, gg);
 #endif
 #pragma unroll
                 for (int k = 0; k < T; ++k) {
@@ -470,15 +470,15 @@ __device__ __forceinline__ void scan_bwd4_body(const BwdArgs& q, float* smem, in
 #pragma unroll
                     for (int k = 0; k < T; ++k) asm volatile("" :: "v"(duv[k]), "v"(ddv[k]));
 #else
-                    store10<REV>(du_row, lbase_e, L, vec, duv);
-                    store10<REV>(dd_row, lbase_e, L, vec, ddv);
+                    store_items<float, T, REV>(du_row, lbase_e, L, vec, duv);
+                    store_items<float, T, REV>(dd_row, lbase_e, L, vec, ddv);
 #endif
                 } else {
                     const int rpg2 = ke->f.rows_per_group;
                     const int ur2 = r_e - ((g - (g >> ke->f.u_gshift)) * rpg2);
                     const float* __restrict__ u_row2 = reinterpret_cast<const float*>(ke->f.u) + (long)b * ke->f.u_bs + (long)ur2 * ke->f.u_ds;
                     float uu[T];
-                    load10<REV>(u_row2, lbase_e, L, vec, uu);
+                    load_items<float, T, REV>(u_row2, lbase_e, L, vec, uu);
                     float duv[T], ddv[T];
 #pragma unroll
                     for (int k = 0; k < T; ++k) {
@@ -486,8 +486,8 @@ __device__ __forceinline__ void scan_bwd4_body(const BwdArgs& q, float* smem, in
                         ddv[k] = fmaf(uu[k], sdxB[k], sAx[k]);
                         dbias_acc += (lbase_e + k < L) ? ddv[k] : 0.0f;
                     }
-                    store10<REV>(du_row, lbase_e, L, vec, duv);
-                    store10<REV>(dd_row, lbase_e, L, vec, ddv);
+                    store_items<float, T, REV>(du_row, lbase_e, L, vec, duv);
+                    store_items<float, T, REV>(dd_row, lbase_e, L, vec, ddv);
                 }
             }
 #if !(SIGMA_BWD4_ABL & 2)

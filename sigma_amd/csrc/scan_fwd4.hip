@@ -65,8 +65,8 @@ __device__ __forceinline__ void scan_fwd4_body(const FwdArgs& p, float* smem, in
     };
     stage(0, 0);
     float uv[T], dv[T];
-    load10<REV>(u_row, li * T, L, vec, uv);
-    load10<REV>(d_row, li * T, L, vec, dv);
+    load_items<float, T, REV>(u_row, li * T, L, vec, uv);
+    load_items<float, T, REV>(d_row, li * T, L, vec, dv);
     lds_dma_wait();
     __syncthreads();
 
@@ -89,8 +89,8 @@ __device__ __forceinline__ void scan_fwd4_body(const FwdArgs& p, float* smem, in
             dsum += d;
         }
         if (j + 1 < ntiles) {                          // next tile's u / delta fly during the state loop
-            load10<REV>(u_row, lbase + kTile4, L, vec, uv);
-            load10<REV>(d_row, lbase + kTile4, L, vec, dv);
+            load_items<float, T, REV>(u_row, lbase + kTile4, L, vec, uv);
+            load_items<float, T, REV>(d_row, lbase + kTile4, L, vec, dv);
         }
 
         float Xn = 0.0f;                               // states leaving this tile, collected state by state
@@ -141,7 +141,7 @@ __device__ __forceinline__ void scan_fwd4_body(const FwdArgs& p, float* smem, in
             Xn = li15 ? x : rot;
         }
         Xv = Xn;
-        store10<REV>(o_row, lbase, L, vec, y);
+        store_items<float, T, REV>(o_row, lbase, L, vec, y);
         if (x_row != nullptr && li >= vshift) x_row[(long)j * N + (li - vshift)] = Xv;   // checkpoint j = state after tile j
         lds_dma_wait();
         __syncthreads();                               // next image landed; this one consumed by every wave

@@ -62,60 +62,6 @@ __device__ __forceinline__ void touch_line4(const char* pa, bool on, unsigned ld
     }
 }
 
-// ---- a lane's 10 consecutive row elements with 16-byte accesses -------------------------------------------------------
-// The lane segment starts at an EVEN element index of a 16-byte aligned row (tile starts are multiples of 160, lanes
-// step by 10; reversed groups need L % 4 == 0 on the vector path), so its first element is 0 or 2 mod 4: a lane whose
-// segment is 16-byte aligned moves elements [0..3], [4..7] as dwordx4 and [8, 9] as dwordx2, its neighbour (8 bytes
-// off) [2..5], [6..9] and [0, 1] -- three memory instructions of one width per array and row step instead of five
-// 8-byte ones (each of which touches all 20 cache lines of the wave's 4 x 640-byte footprint: the u / delta / dout loads
-// were 7.5 % and the du / ddelta stores 10 % of scan_bwd4's time, profiles/r03_bwd4_ablation.txt), plus ten selects.
-template <bool REV>
-__device__ __forceinline__ void load10(const float* __restrict__ row, int lbase, int L, bool vec, float (&v)[kT4]) {
-    if (vec && lbase + kT4 <= L) {
-        const int start = REV ? (L - lbase - kT4) : lbase;
-        const bool a = (start & 3) == 0;
-        const float* __restrict__ p = row + start;
-        const float4 q1 = *reinterpret_cast<const float4*>(p + (a ? 0 : 2));
-        const float4 q2 = *reinterpret_cast<const float4*>(p + (a ? 4 : 6));
-        const float2 q3 = *reinterpret_cast<const float2*>(p + (a ? 8 : 0));
-        float m[kT4];
-        m[0] = a ? q1.x : q3.x; m[1] = a ? q1.y : q3.y;
-        m[2] = a ? q1.z : q1.x; m[3] = a ? q1.w : q1.y;
-        m[4] = a ? q2.x : q1.z; m[5] = a ? q2.y : q1.w;
-        m[6] = a ? q2.z : q2.x; m[7] = a ? q2.w : q2.y;
-        m[8] = a ? q3.x : q2.z; m[9] = a ? q3.y : q2.w;
-#pragma unroll
-        for (int k = 0; k < kT4; ++k) v[k] = m[REV ? kT4 - 1 - k : k];
-    } else {
-#pragma unroll
-        for (int k = 0; k < kT4; ++k) {
-            const int pos = lbase + k;
-            v[k] = (pos < L) ? row[REV ? (L - 1 - pos) : pos] : 0.0f;
-        }
-    }
-}
-
-template <bool REV>
-__device__ __forceinline__ void store10(float* __restrict__ row, int lbase, int L, bool vec, const float (&v)[kT4]) {
-    if (vec && lbase + kT4 <= L) {
-        const int start = REV ? (L - lbase - kT4) : lbase;
-        const bool a = (start & 3) == 0;
-        float m[kT4];
-#pragma unroll
-        for (int k = 0; k < kT4; ++k) m[k] = v[REV ? kT4 - 1 - k : k];
-        float* __restrict__ p = row + start;
-        *reinterpret_cast<float4*>(p + (a ? 0 : 2)) = a ? make_float4(m[0], m[1], m[2], m[3]) : make_float4(m[2], m[3], m[4], m[5]);
-        *reinterpret_cast<float4*>(p + (a ? 4 : 6)) = a ? make_float4(m[4], m[5], m[6], m[7]) : make_float4(m[6], m[7], m[8], m[9]);
-        *reinterpret_cast<float2*>(p + (a ? 8 : 0)) = a ? make_float2(m[8], m[9]) : make_float2(m[0], m[1]);
-    } else {
-#pragma unroll
-        for (int k = 0; k < kT4; ++k) {
-            const int pos = lbase + k;
-            if (pos < L) row[REV ? (L - 1 - pos) : pos] = v[k];
-        }
-    }
-}
-
 // positions 2q, 2q+1 of the lane's 10 (li = lane inside its DPP row); the image is in memory order
 template <bool REV>
 __device__ __forceinline__ void lds_read_pair(const float* __restrict__ tile, int li, int q, float (&v)[2]) {

@@ -87,6 +87,10 @@ class EncoderDecoder(nn.Module):
         """backbone -> decoder -> bilinear resize to the input size (builder.py:128-144)."""
         feats = self.backbone(rgb, modal_x)
         out = self.decode_head(feats)
+        if tuple(out.shape[2:]) == tuple(rgb.shape[2:]):
+            # builder.py:135 resizes to the input size; the Mamba decoder already delivers it, and a bilinear resize to the
+            # same size (align_corners=False) is the identity (source index == destination index, weight 1): skipped
+            return out
         return F.interpolate(out, size=rgb.shape[2:], mode="bilinear", align_corners=False)
 
     def forward(self, rgb, modal_x, label=None):
