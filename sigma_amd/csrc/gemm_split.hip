@@ -94,7 +94,8 @@ typedef float f32x4_t __attribute__((ext_vector_type(4)));
 template <int ROWS, bool KS>
 struct TileLoader {
     static constexpr int NV = KS ? ((ROWS + 127) / 128) * 4 : ROWS / 32;    // 16-byte loads per thread and stage
-    unsigned off[NV];
+    static constexpr int NOFF = KS ? NV / 4 : NV;                           // KS: the four k-rows of a chunk are ld apart
+    unsigned off[NOFF];
 
     // row0: first row of the tile, nrows: rows of the operand (tail rows repeat the last valid row / chunk: their
     // products are masked at the C store)
@@ -114,8 +115,7 @@ struct TileLoader {
                 ch = ch < ROWS / 4 ? ch : ROWS / 4 - 1;                   // lanes past the tile repeat its last chunk
                 long row = row0 + 4L * ch;
                 row = row + 4 <= nrows ? row : nrows - 4;                 // nrows % 4 == 0, row0 % 4 == 0 (host-checked)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) off[4 * i + j] = (unsigned)(((long)(((t & 7) << 2) + j) * ld + (row - row0)) * 4);
+                off[i] = (unsigned)(((long)((t & 7) << 2) * ld + (row - row0)) * 4);
             }
         }
     }
@@ -128,9 +128,10 @@ struct TileLoader {
         for (int i = 0; i < NV; ++i) { v[i] = f32x4_t{0.5f + t, 0.25f, 1.0f + i, 2.0f}; asm volatile("" : "+v"(v[i])); }
         return;
 #endif
+        const unsigned ldb4 = (unsigned)(ld * 4);
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            unsigned o = off[i];
+            unsigned o = KS ? off[i >> 2] + (unsigned)(i & 3) * ldb4 : off[i];
             if (rem < kBK) {                                              // wave-uniform: the last, partial k-step
                 if constexpr (!KS) {
                     const int kc = (t & 7) << 2;
@@ -185,10 +186,15 @@ struct TileLoader {
 template <int N>
 __device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 
+// k-steps of operands in flight per workgroup (register ring).  Measured (profiles/r03_gemm_depth.txt): with both
+// operands k-contiguous or one of them transposed, one step ahead is as fast as two (and leaves the registers to the
+// compiler's schedule); the weight-gradient form (both operands transposed on the way in, reduction over the tokens
+// straight from HBM) gains 10-20 % from two on the long-token shapes.
 #ifndef SIGMA_GEMM_DEPTH
-#define SIGMA_GEMM_DEPTH 2
+#define SIGMA_GEMM_DEPTH 0
 #endif
-constexpr int kDepth = SIGMA_GEMM_DEPTH;   // k-steps of operands in flight per workgroup (register ring)
+template <bool A_KS, bool B_KS>
+struct ring_depth { static constexpr int value = SIGMA_GEMM_DEPTH ? SIGMA_GEMM_DEPTH : ((A_KS && B_KS) ? 2 : 1); };
 
 // one output tile (x one reduction slice) of one problem of the batch
 struct Item {
@@ -208,6 +214,7 @@ gemm_split3_kernel(const GemmArgs g) {
     constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
     static_assert(TM >= 1 && TN >= 1 && TM * 32 * WM == BM && TN * 32 * WN == BN, "tile shape");
     static_assert(P == 2 || P == 3, "two or three bf16 pieces per operand");
+    constexpr int kDepth = ring_depth<A_KS, B_KS>::value;
     static_assert(kDepth >= 1 && kDepth <= 3, "ring depth");
     __shared__ __attribute__((aligned(16))) uint16_t smem[P * (BM + BN) * kPitch];
     uint16_t* sA = smem;                               // [P][BM][kPitch]

@@ -173,6 +173,16 @@ class MambaDecoder(nn.Module):
 
     def up_x4(self, x, pz):
         x = self.up(x)                                            # (B, 4H, 4W, C)
+        if x.is_cuda and x.dtype == torch.float32 and self.output.bias is None:
+            # the 1x1 classifier (MambaDecoder.py:189, 276-280) as a GEMM over the channels-last tokens: the reference's
+            # conv wants (B, C, 4H, 4W), i.e. a transposing copy of the largest activation of the model (944 MB at batch 8)
+            # and a weight gradient with the strides of a (nc, C, 1, 1) view that DistributedDataParallel has to re-lay
+            # (the "Grad strides do not match bucket view strides" warning of round 2).  The logits come back as a
+            # (B, nc, 4H, 4W) VIEW of the channels-last result.
+            from ...gemm import gemm_mode, linear
+            w2 = self.output.weight.view(self.output.weight.shape[0], -1)
+            y = linear(x, w2) if gemm_mode() == "split3" else F.linear(x, w2)
+            return y.permute(0, 3, 1, 2)
         return self.output(x.permute(0, 3, 1, 2))
 
     def forward(self, inputs):

@@ -40,7 +40,9 @@ class RGBXTransformer(nn.Module):
         for i, f in enumerate(feats):
             f = f.permute(0, 2, 3, 1)                                # NHWC views
             c_rgb, c_e = self.cross_mamba[i](f[:B], f[B:])           # CroMB
-            fused.append(self.channel_attn_mamba[i](c_rgb, c_e).permute(0, 3, 1, 2).contiguous())  # ConMB -> NCHW
+            # ConMB -> (B, C, H, W) for the decoder (dual_vmamba.py:100-104), as a channels-last view: the decoder
+            # permutes back to (B, H, W, C) at once (MambaDecoder.py:222-232), so no NCHW copy is made and undone
+            fused.append(self.channel_attn_mamba[i](c_rgb, c_e).permute(0, 3, 1, 2))
         return fused
 
     def forward(self, x_rgb, x_e):

@@ -60,6 +60,17 @@ class DropPath(nn.Module):
             mask.div_(keep)
         return x * mask
 
+    def add_to(self, residual: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+        """residual + drop_path(x) as ONE elementwise pass (addcmul with the per-sample mask) instead of a multiply and an
+        add over the whole activation; same random draw, same values."""
+        if self.drop_prob == 0.0 or not self.training:
+            return residual + x
+        keep = 1.0 - self.drop_prob
+        mask = x.new_empty((x.shape[0],) + (1,) * (x.dim() - 1)).bernoulli_(keep)
+        if keep > 0.0:
+            mask.div_(keep)
+        return torch.addcmul(residual, x, mask)
+
     def extra_repr(self) -> str:
         return f"drop_prob={self.drop_prob:.3f}"
 
@@ -269,7 +280,7 @@ class VSSBlock(nn.Module):
         self.drop_path = DropPath(drop_path)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        return x + self.drop_path(self.op(self.norm(x)))
+        return self.drop_path.add_to(x, self.op(self.norm(x)))
 
 
 # --------------------------------------------------------------------------- decoder block
@@ -327,9 +338,12 @@ class CVSSDecoderBlock(nn.Module):
         self.scale2 = nn.Parameter(torch.ones(hidden_dim))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:       # (B, H, W, C)
-        x = x * self.scale1 + self.drop_path(self.op(self.norm1(x)))
+        x = self.drop_path.add_to(x * self.scale1, self.op(self.norm1(x)))
         y = self.conv_blk(self.norm2(x).permute(0, 3, 1, 2).contiguous())
-        return y.permute(0, 2, 3, 1) + x * self.scale2
+        # the channels-last operand first: the sum then comes out contiguous in (B, H, W, C) and the next block's
+        # LayerNorm / in_proj read it in place (with the permuted conv output first, the result inherited its NCHW
+        # strides and every following LayerNorm started with a transposing copy: 7 x 413 MB per step at 120 x 160)
+        return x * self.scale2 + y.permute(0, 2, 3, 1)
 
 
 # --------------------------------------------------------------------------- CroMB
@@ -414,7 +428,7 @@ class CrossMambaFusionBlock(nn.Module):
 
     def forward(self, x_rgb, x_e):
         c_rgb, c_e = self.op(x_rgb, x_e)
-        return x_rgb + self.drop_path1(c_rgb), x_e + self.drop_path2(c_e)
+        return self.drop_path1.add_to(x_rgb, c_rgb), self.drop_path2.add_to(x_e, c_e)
 
 
 # --------------------------------------------------------------------------- ConMB
@@ -508,7 +522,7 @@ class ConcatMambaFusionBlock(nn.Module):
         self.drop_path = DropPath(drop_path)
 
     def forward(self, x_rgb, x_e):
-        return x_rgb + x_e + self.drop_path(self.op(x_rgb, x_e))
+        return self.drop_path.add_to(x_rgb + x_e, self.op(x_rgb, x_e))
 
 
 # --------------------------------------------------------------------------- backbone
@@ -595,5 +609,7 @@ class Backbone_VSSM(nn.Module):
             o = layer.blocks(x)
             x = layer.downsample(o)
             if i in self.out_indices:
-                outs.append(getattr(self, f"outnorm{i}")(o).permute(0, 3, 1, 2).contiguous())
+                # (B, C, H, W) as the reference returns it (vmamba.py:2200-2206), but as a channels-last VIEW: the fusion blocks
+                # permute straight back to (B, H, W, C), so the reference's contiguous() copy would only be undone again
+                outs.append(getattr(self, f"outnorm{i}")(o).permute(0, 3, 1, 2))
         return outs if self.out_indices else x
