@@ -119,7 +119,7 @@ int sigma_split_bf16(const float *src, int64_t rows, int64_t cols, int64_t src_r
  *       tensor: every LayerNorm of the hot path (vmamba.py:617, 724, 1183-1184, 1448-1449, 1693,
  *       1783, 1797; MambaDecoder.py:18, 41, 85).  C % 4 == 0, C <= 2048.
  *       bwd: dx fully written; dgamma / dbeta fully written (deterministic two-stage column sums
- *       through `workspace` of sigma_layernorm_bwd_partial_rows(rows) * 2 * C floats).
+ *       through `workspace` of sigma_layernorm_bwd_partial_rows(rows, C) * 2 * C floats).
  *       bwd with a gate needs beta as well (the normalised value is recomputed).                  */
 typedef struct sigma_layernorm_params {
     int64_t rows;
@@ -146,7 +146,7 @@ typedef struct sigma_layernorm_params {
 
 int sigma_layernorm_fwd(const sigma_layernorm_params *params, void *stream);
 int sigma_layernorm_bwd(const sigma_layernorm_params *params, void *stream);
-int sigma_layernorm_bwd_partial_rows(int64_t rows);
+int sigma_layernorm_bwd_partial_rows(int64_t rows, int32_t channels);
 
 #ifdef __cplusplus
 }

@@ -185,7 +185,7 @@ def load() -> ctypes.CDLL:
     for name in OPS_SYMBOLS:
         fn = getattr(lib, name)
         if name == "sigma_layernorm_bwd_partial_rows":
-            fn.argtypes = [ctypes.c_int64]
+            fn.argtypes = [ctypes.c_int64, ctypes.c_int32]
         elif name == "sigma_pair_sum_add":
             fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]
         elif name == "sigma_upsample2x_nhwc":

@@ -15,16 +15,17 @@
 #include <stdint.h>
 
 #include "../../include/sigma_ops.h"
+#include "scan_device.h"
 
 namespace sigma {
 
 namespace {
 
-__device__ __forceinline__ float wave_allsum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
+// Sum over the 64 lanes, result in every lane: six DPP adds (row_shr 1/2/4/8, row_bcast 15/31) + v_readlane 63
+// (scan_device.h wave_sum).  Round 2 used __shfl_xor here, i.e. six ds_bpermute_b32 per sum through the LDS crossbar
+// (24 clocks each, tools/ubench/issue_ubench.hip) in a dependent chain: 12-24 of them per row made the backward
+// latency-bound at 0.17-0.37 of the copy ceiling (profiles/r03_aux_roofline.jsonl).
+__device__ __forceinline__ float wave_allsum(float v) { return wave_sum(v); }
 
 struct LnArgs {
     const float* x; const float* gamma; const float* beta; const float* dy;
@@ -228,7 +229,14 @@ int grid_blocks(long M, long cap = 2048) {   // 2048 blocks = 8192 waves: 8 per 
     if (b < 1) b = 1;
     return (int)b;
 }
-constexpr long kBwdBlocks = 512;             // one partial dgamma/dbeta row per wave: 2048 rows to add
+constexpr long kBwdBlocks = 512;             // floor: one partial dgamma/dbeta row per wave, 2048 rows to add
+// waves of the backward: up to 8 per SIMD while the partial rows (2 x C floats per wave) stay within 8 MB
+long bwd_blocks(long rows, int C) {
+    long cap = (8L << 20) / (8L * C) / 4;    // workgroups of 4 waves
+    if (cap > 2048) cap = 2048;
+    if (cap < kBwdBlocks) cap = kBwdBlocks;
+    return cap;
+}
 
 bool check(const sigma_layernorm_params* p) {
     return p && p->rows >= 0 && p->channels > 0 && p->channels % 4 == 0 && p->channels <= 2048;
@@ -240,7 +248,9 @@ bool check(const sigma_layernorm_params* p) {
 
 extern "C" {
 
-int sigma_layernorm_bwd_partial_rows(int64_t rows) { return sigma::grid_blocks(rows, sigma::kBwdBlocks) * 4; }
+int sigma_layernorm_bwd_partial_rows(int64_t rows, int32_t channels) {
+    return sigma::grid_blocks(rows, sigma::bwd_blocks(rows, channels > 0 ? channels : 4)) * 4;
+}
 
 int sigma_layernorm_fwd(const sigma_layernorm_params* p, void* stream) {
     if (!sigma::check(p)) return SIGMA_OPS_ERR_ARG;
@@ -264,7 +274,7 @@ int sigma_layernorm_bwd(const sigma_layernorm_params* p, void* stream) {
     if (!sigma::check(p)) return SIGMA_OPS_ERR_ARG;
     if (!p->dgamma) return SIGMA_OPS_ERR_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const int grid = sigma::grid_blocks(p->rows, sigma::kBwdBlocks);
+    const int grid = sigma::grid_blocks(p->rows, sigma::bwd_blocks(p->rows, p->channels));
     if (p->rows > 0) {
         if (!p->x || !p->gamma || !p->dy || !p->mean || !p->rstd || !p->dx || !p->workspace) return SIGMA_OPS_ERR_ARG;
         sigma::LnArgs a{};

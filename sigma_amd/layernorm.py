@@ -73,7 +73,7 @@ class LayerNormFn(torch.autograd.Function):
         dx = torch.empty_like(xc)
         dgamma = torch.empty_like(weight)
         dbeta = torch.empty_like(weight) if ctx.has_bias else None
-        nrows = int(lib.sigma_layernorm_bwd_partial_rows(rows))
+        nrows = int(lib.sigma_layernorm_bwd_partial_rows(rows, C))
         ws = torch.empty(max(nrows, 1) * 2 * C, device=xc.device, dtype=torch.float32)
         p = _capi.LayerNormParams()
         p.rows, p.channels, p.eps = rows, C, ctx.eps

@@ -101,6 +101,7 @@ class EncoderDecoder(nn.Module):
                 # identical value for every reduction / ignore_index / class-weight setting of CrossEntropyLoss -- instead
                 # of ATen's (B, C, H, W) path, which starts with a contiguous() copy of the logits
                 nc = out.shape[1]
-                return self.criterion(out.permute(0, 2, 3, 1).reshape(-1, nc), label.long().reshape(-1))
+                loss = self.criterion(out.permute(0, 2, 3, 1).reshape(-1, nc), label.long().reshape(-1))
+                return loss.view(label.shape) if loss.dim() == 1 else loss          # dim 1: reduction "none"
             return self.criterion(out, label.long())
         return out if out.is_contiguous() else out.contiguous()     # callers get the reference's (B, nc, H, W) layout
