@@ -18,6 +18,7 @@
 #include <stdint.h>
 
 #include "../../include/sigma_ops.h"
+#include "scan_device.h"
 
 namespace sigma {
 
@@ -39,11 +40,8 @@ __device__ __forceinline__ float sigmoidf_fast(float v) {
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-v * 1.4426950408889634f));
 }
 
-__device__ __forceinline__ float wave_sum_shfl(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    return v;
-}
+// DPP row / bcast adds (scan_device.h wave_sum) instead of six ds_bpermute per sum: ten sums per tile
+__device__ __forceinline__ float wave_sum_shfl(float v) { return wave_sum(v); }
 
 // taps t[0..8] = x[h-1..h+1][w-1..w+1] (0 outside the plane)
 __device__ __forceinline__ void load_taps(const float* __restrict__ plane, int h, int w, int H, int W, float (&t)[9]) {

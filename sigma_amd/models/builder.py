@@ -96,12 +96,5 @@ class EncoderDecoder(nn.Module):
     def forward(self, rgb, modal_x, label=None):
         out = self.encode_decode(rgb, modal_x)
         if label is not None:
-            if isinstance(self.criterion, nn.CrossEntropyLoss) and out.dim() == 4 and out.stride(1) == 1 and out.shape[1] > 1:
-                # channels-last logits (the decoder's GEMM classifier): the same criterion on the (pixels, classes) view --
-                # identical value for every reduction / ignore_index / class-weight setting of CrossEntropyLoss -- instead
-                # of ATen's (B, C, H, W) path, which starts with a contiguous() copy of the logits
-                nc = out.shape[1]
-                loss = self.criterion(out.permute(0, 2, 3, 1).reshape(-1, nc), label.long().reshape(-1))
-                return loss.view(label.shape) if loss.dim() == 1 else loss          # dim 1: reduction "none"
             return self.criterion(out, label.long())
         return out if out.is_contiguous() else out.contiguous()     # callers get the reference's (B, nc, H, W) layout

@@ -194,12 +194,17 @@ def make_graphed_ddp_step(model: nn.Module, opt, batch: Tuple[torch.Tensor, ...]
             _allreduce_mean(flat, bf16_comm)
             opt.step()
     torch.cuda.current_stream().wait_stream(side)
+    # The process group's watchdog thread polls the events of collectives in flight (hipEventQuery); under the default
+    # "global" capture mode such a call from another thread invalidates the capture and poisons the communicator (the
+    # process then aborts in destroy_process_group).  So: no collective is in flight when the capture starts, and the
+    # capture only polices its own thread.
+    torch.cuda.synchronize()
     g_fb, g_opt = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g_fb):
+    with torch.cuda.graph(g_fb, capture_error_mode="thread_local"):
         flat.zero_()
         loss = model(*static)
         loss.backward()
-    with torch.cuda.graph(g_opt, pool=g_fb.pool()):
+    with torch.cuda.graph(g_opt, pool=g_fb.pool(), capture_error_mode="thread_local"):
         opt.step()
 
     def step():
