@@ -132,6 +132,7 @@ def make_graphed_step(net: nn.Module, opt, batch: Tuple[torch.Tensor, ...], warm
         graph.replay()
         return loss
     step.graph = graph
+    step.static = static            # the graph reads these buffers: they live as long as the step does
     return step, static
 
 
@@ -216,6 +217,7 @@ def make_graphed_ddp_step(model: nn.Module, opt, batch: Tuple[torch.Tensor, ...]
         return loss
     step.graphs = (g_fb, g_opt)
     step.flat = flat
+    step.static = static            # the graphs read these buffers: they live as long as the step does
     return step, static
 
 
