@@ -50,7 +50,7 @@ def main():
         step()
     torch.cuda.synchronize()
     from torch.profiler import profile, ProfilerActivity
-    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True, with_stack=True) as prof:
         step()
         torch.cuda.synchronize()
     agg = collections.defaultdict(lambda: [0.0, 0])
@@ -71,7 +71,16 @@ def main():
                 break
             top = p.name
             p = p.cpu_parent
-        key = (("bwd " + node) if node else ("fwd " + top), e.name, str(e.input_shapes)[:70])
+        site = ""
+        if node is None:                              # forward: the innermost sigma_amd frame of the Python stack
+            q = e
+            while q is not None and not site:
+                for fr in (q.stack or []):
+                    if "sigma_amd" in fr:
+                        site = " @" + fr.split("sigma_amd/")[-1][:60]
+                        break
+                q = q.cpu_parent
+        key = (("bwd " + node) if node else ("fwd " + top + site), e.name, str(e.input_shapes)[:70])
         agg[key][0] += t
         agg[key][1] += 1
         tot += t
@@ -83,7 +92,7 @@ def main():
         print(f"{t / 1e3:8.2f} ms  {node}")
     print()
     for (node, op, sh), (t, c) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:60]:
-        print(f"{t / 1e3:8.2f} ms x{c:<4d} {node[:44]:44s} {op:14s} {sh}")
+        print(f"{t / 1e3:8.2f} ms x{c:<4d} {node[:84]:84s} {op:14s} {sh}")
 
 
 if __name__ == "__main__":
