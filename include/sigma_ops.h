@@ -102,6 +102,49 @@ int sigma_pair_sum_add(const float *src, float *acc, int64_t n_outer, int64_t in
 int sigma_upsample2x_nhwc(const float *in, float *out, int32_t batch, int32_t height, int32_t width, int32_t channels,
                           int32_t backward, void *stream);
 
+/*   sigma_plane_pool / sigma_plane_scale / sigma_plane_dot / sigma_plane_gate_bwd
+ *       ChannelAttention of the decoder's conv branch (vmamba.py:1725-1741; called from ChannelAttentionBlock :1744-1757
+ *       inside CVSSDecoderBlock :1800-1805):  y = x * sigmoid(fc(avg_pool(x)) + fc(max_pool(x)))  on contiguous
+ *       (B, C, H, W) fp32 activations, seen here as `planes` = B * C planes of `hw` = H * W floats.
+ *           pool     : mean[p], max[p], count[p] = number of elements of plane p equal to its max (one pass over x)
+ *           scale    : out[p][i] = x[p][i] * scale[p]
+ *           dot      : out[p] = sum_i a[p][i] * b[p][i]          (d/d scale of the product: a = dy, b = x)
+ *           gate_bwd : dx[p][i] = g[p][i] * scale[p] + dmean[p] / hw + (x[p][i] == max[p] ? dmax[p] / count[p] : 0)
+ *       -- the gradient of the max pool is shared by tied maxima, as torch.amax does (the reference's
+ *       AdaptiveMaxPool2d routes it to one of them; the two agree wherever the maximum is unique).  The tiny (2B, C)
+ *       squeeze/excite MLP between pool and scale stays with the caller.                                          */
+int sigma_plane_pool(const float *x, int64_t planes, int64_t hw, float *mean, float *max, float *count, void *stream);
+int sigma_plane_scale(const float *x, const float *scale, float *out, int64_t planes, int64_t hw, void *stream);
+int sigma_plane_dot(const float *a, const float *b, float *out, int64_t planes, int64_t hw, void *stream);
+typedef struct sigma_gate_bwd_params {
+    int64_t planes, hw;
+    const float *g;        /* (planes, hw) gradient of the gated output                     */
+    const float *x;        /* (planes, hw) input of the gate                                */
+    const float *scale;    /* (planes) sigmoid gate of the forward                          */
+    const float *dmean;    /* (planes) gradient of the pooled means                         */
+    const float *dmax;     /* (planes) gradient of the pooled maxima                        */
+    const float *max;      /* (planes) pooled maxima of the forward                         */
+    const float *count;    /* (planes) ties of the forward                                  */
+    float *dx;             /* (planes, hw) fully written                                    */
+} sigma_gate_bwd_params;
+int sigma_plane_gate_bwd(const sigma_gate_bwd_params *params, void *stream);
+
+/*   sigma_softmax_ce_fwd / sigma_softmax_ce_bwd
+ *       nn.CrossEntropyLoss(reduction='mean', ignore_index) of models/builder.py:146-166 (criterion built in
+ *       train.py:95) on channels-last logits: `rows` pixels of `classes` contiguous fp32 logits (classes % 4 == 0,
+ *       16-byte aligned), int64 labels.
+ *           fwd : lse[r] = log sum_c exp(logit[r][c]);  partial[2k], partial[2k+1] = (sum of lse[r] - logit[r][label[r]],
+ *                 number of pixels) over the pixels workgroup k < SIGMA_CE_BLOCKS handled with label != ignore_index
+ *                 (labels outside [0, classes) count as ignored; the reference asserts on them).  The caller adds the
+ *                 SIGMA_CE_BLOCKS pairs: loss = sum / count, deterministic.
+ *           bwd : dlogits[r][c] = (exp(logit[r][c] - lse[r]) - [c == label[r]]) * scale[0], zero for ignored pixels;
+ *                 scale = upstream gradient / count, a DEVICE scalar (no host synchronisation).                   */
+#define SIGMA_CE_BLOCKS 1024
+int sigma_softmax_ce_fwd(const float *logits, const int64_t *labels, int64_t rows, int32_t classes, int64_t ignore_index,
+                         float *lse, float *partial, void *stream);
+int sigma_softmax_ce_bwd(const float *logits, const int64_t *labels, const float *lse, const float *scale, int64_t rows,
+                         int32_t classes, int64_t ignore_index, float *dlogits, void *stream);
+
 /*   sigma_split_bf16
  *       Operand images of the split-operand bf16 GEMM (sigma_amd/split_linear.py; the nn.Linear calls of
  *       vmamba.py, e.g. SS2D.in_proj / out_proj :1067-1089): with hi = bf16(x) and lo = bf16(x - hi), row r of the

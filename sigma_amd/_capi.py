@@ -120,13 +120,25 @@ class GemmParams(ctypes.Structure):
     ]
 
 
+class GateBwdParams(ctypes.Structure):
+    """mirror of sigma_gate_bwd_params (include/sigma_ops.h)"""
+    _fields_ = [
+        ("planes", ctypes.c_int64), ("hw", ctypes.c_int64),
+        ("g", ctypes.c_void_p), ("x", ctypes.c_void_p), ("scale", ctypes.c_void_p), ("dmean", ctypes.c_void_p),
+        ("dmax", ctypes.c_void_p), ("max", ctypes.c_void_p), ("count", ctypes.c_void_p), ("dx", ctypes.c_void_p),
+    ]
+
+
+SIGMA_CE_BLOCKS = 1024      # include/sigma_ops.h
+
 # every symbol include/sigma_gemm.h declares
 GEMM_SYMBOLS = ("sigma_gemm_nt_split3", "sigma_gemm_nn_split3", "sigma_gemm_tn_split3")
 
 # every symbol include/sigma_ops.h declares
 OPS_SYMBOLS = ("sigma_dwconv3x3_silu_fwd", "sigma_dwconv3x3_silu_bwd", "sigma_cross_merge_nhwc", "sigma_cross_split_nhwc",
                "sigma_layernorm_fwd", "sigma_layernorm_bwd", "sigma_layernorm_bwd_partial_rows", "sigma_transpose2d",
-               "sigma_pair_sum_add", "sigma_split_bf16", "sigma_upsample2x_nhwc")
+               "sigma_pair_sum_add", "sigma_split_bf16", "sigma_upsample2x_nhwc", "sigma_plane_pool", "sigma_plane_scale",
+               "sigma_plane_dot", "sigma_plane_gate_bwd", "sigma_softmax_ce_fwd", "sigma_softmax_ce_bwd")
 
 # every symbol include/sigma_scan.h declares; tests check the library exports all of them
 EXPORTED_SYMBOLS = (
@@ -191,6 +203,18 @@ def load() -> ctypes.CDLL:
         elif name == "sigma_upsample2x_nhwc":
             fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32,
                            ctypes.c_int32, ctypes.c_void_p]
+        elif name == "sigma_plane_pool":
+            fn.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        elif name in ("sigma_plane_scale", "sigma_plane_dot"):
+            fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]
+        elif name == "sigma_plane_gate_bwd":
+            fn.argtypes = [P(GateBwdParams), ctypes.c_void_p]
+        elif name == "sigma_softmax_ce_fwd":
+            fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p,
+                           ctypes.c_void_p, ctypes.c_void_p]
+        elif name == "sigma_softmax_ce_bwd":
+            fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
+                           ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]
         elif name == "sigma_split_bf16":
             fn.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
                            ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]

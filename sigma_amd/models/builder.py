@@ -96,5 +96,9 @@ class EncoderDecoder(nn.Module):
     def forward(self, rgb, modal_x, label=None):
         out = self.encode_decode(rgb, modal_x)
         if label is not None:
-            return self.criterion(out, label.long())
+            # mean cross entropy straight from the channels-last logits of the classifier GEMM (csrc/pointwise.hip); any
+            # other criterion / layout: the criterion itself on the (B, nc, H, W) view
+            from ..pointwise import cross_entropy
+            loss = cross_entropy(self.criterion, out, label) if out.is_cuda else None
+            return loss if loss is not None else self.criterion(out, label.long())
         return out if out.is_contiguous() else out.contiguous()     # callers get the reference's (B, nc, H, W) layout

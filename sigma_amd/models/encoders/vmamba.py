@@ -33,6 +33,8 @@ import torch.nn.functional as F
 import os
 
 from ...selective_scan import selective_scan_fn
+from ...layout import channels_first, channels_last, transpose_rows
+from ...pointwise import channel_gate, channel_gate_ok
 from ...ss2d_fused import (dwconv_silu, dwconv_silu_two_orders, selective_scan_ext, split_xz, ss2d_core,
                            ss2d_core_from_orders)
 
@@ -81,6 +83,10 @@ class Permute(nn.Module):
         self.dims = dims
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if self.dims == (0, 2, 3, 1) and x.is_cuda and x.dim() == 4 and x.is_contiguous():
+            # patch_embed: conv (B, C, H, W) -> LayerNorm over C.  The LayerNorm needs contiguous rows: make them with the
+            # tiled transpose (and hand the conv a contiguous gradient) instead of a strided ATen copy each way
+            return channels_last(x)
         return x.permute(*self.dims)
 
 
@@ -299,6 +305,9 @@ class ChannelAttention(nn.Module):
         self.sigmoid = nn.Sigmoid()
 
     def forward(self, x):
+        w1, w2 = self.fc[0].weight, self.fc[2].weight
+        if x.is_cuda and channel_gate_ok(x, w1, w2) and isinstance(self.fc[1], nn.SiLU):
+            return channel_gate(x, w1, w2)              # one pooling pass + one scaling pass (csrc/pointwise.hip)
         # global pools as plain reductions (AdaptiveMaxPool2d(1) runs a 0.9 ms one-thread-per-output
         # kernel on ROCm and keeps an index tensor for backward); same values and gradients
         pooled = torch.cat([x.mean(dim=(2, 3), keepdim=True), x.amax(dim=(2, 3), keepdim=True)], dim=0)
@@ -339,10 +348,14 @@ class CVSSDecoderBlock(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:       # (B, H, W, C)
         x = self.drop_path.add_to(x * self.scale1, self.op(self.norm1(x)))
-        y = self.conv_blk(self.norm2(x).permute(0, 3, 1, 2).contiguous())
+        y = self.conv_blk(channels_first(self.norm2(x)))
         # the channels-last operand first: the sum then comes out contiguous in (B, H, W, C) and the next block's
         # LayerNorm / in_proj read it in place (with the permuted conv output first, the result inherited its NCHW
         # strides and every following LayerNorm started with a transposing copy: 7 x 413 MB per step at 120 x 160)
+        if y.is_cuda:
+            # conv branch back to channels-last with the tiled transpose (its gradient then arrives contiguous in the
+            # (B, C, H, W) order the gate's backward reads), residual scale + add in one pass
+            return torch.addcmul(channels_last(y), x, self.scale2)
         return x * self.scale2 + y.permute(0, 2, 3, 1)
 
 
@@ -371,9 +384,11 @@ class Cross_Mamba_Attention_SSM(nn.Module):
 
     def _project(self, x_seq, x_proj, dt_proj):
         """x_seq (B, d, L) -> delta (B, d, L), B (B, N, L), C (B, N, L); bias enters via delta_bias."""
-        dbl = torch.matmul(x_proj.weight, x_seq)                     # (B, R+2N, L)
+        # the weights as a broadcast batch: matmul(2-D, 3-D) folds the batch into the rows of ONE GEMM and for that
+        # copies the activations into (B, L, d) order first (2 x 59 MB per call at 120 x 160)
+        dbl = torch.matmul(x_proj.weight.unsqueeze(0), x_seq)        # (B, R+2N, L)
         dt, Bm, Cm = torch.split(dbl, [self.dt_rank, self.d_state, self.d_state], dim=1)
-        return torch.matmul(dt_proj.weight, dt), Bm.contiguous(), Cm.contiguous()
+        return torch.matmul(dt_proj.weight.unsqueeze(0), dt), Bm, Cm   # B / C: row slices, read in place by the scan
 
     def forward(self, x_rgb: torch.Tensor, x_e: torch.Tensor):   # both (B, d, L) channel-major sequences
         dt_rgb, B_rgb, C_rgb = self._project(x_rgb, self.x_proj_1, self.dt_proj_1)
@@ -382,7 +397,7 @@ class Cross_Mamba_Attention_SSM(nn.Module):
                                   self.dt_proj_1.bias.float(), True)
         y_e = selective_scan_fn(x_e, dt_e, -torch.exp(self.A_log_2.float()), B_e, C_rgb, self.D_2.float(),
                                 self.dt_proj_2.bias.float(), True)
-        return self.out_norm_1(y_rgb.transpose(1, 2)), self.out_norm_2(y_e.transpose(1, 2))   # (B, L, d)
+        return self.out_norm_1(transpose_rows(y_rgb)), self.out_norm_2(transpose_rows(y_e))   # (B, L, d)
 
 
 class CrossMambaFusion_SS2D_SSM(nn.Module):
@@ -406,8 +421,8 @@ class CrossMambaFusion_SS2D_SSM(nn.Module):
 
     def forward(self, x_rgb: torch.Tensor, x_e: torch.Tensor):   # (B, H, W, C) each
         B, H, W, _ = x_rgb.shape
-        both = torch.cat([self.in_proj(x_rgb), self.in_proj_modalx(x_e)], dim=0)      # shared conv: one launch
-        both = _conv_act(self.conv2d, self.act, both.permute(0, 3, 1, 2).contiguous()).flatten(2)  # (2B, d, L)
+        both = torch.cat([channels_first(self.in_proj(x_rgb)), channels_first(self.in_proj_modalx(x_e))], dim=0)
+        both = _conv_act(self.conv2d, self.act, both).flatten(2)      # shared conv: one launch; (2B, d, L)
         b_rgb, b_e = both.split(B, dim=0)             # split: the backward is ONE cat (two slices: 2 x zero fill + copy + add)
         y_rgb, y_e = self.CMA_ssm(b_rgb, b_e)
         y_rgb = self.dropout_rgb(self.out_proj_rgb(y_rgb.view(B, H, W, -1)))
@@ -473,19 +488,18 @@ class ConMB_SS2D(nn.Module):
         R, N = self.dt_rank, self.d_state
         c = R + 2 * N
         seq = torch.cat([c_rgb.flatten(2), c_e.flatten(2)], dim=2)               # (B, d, 2HW): rgb tokens first
-        p = torch.matmul(self.x_proj_weight.reshape(2 * c, d), seq)              # both directions in one GEMM
+        p = torch.matmul(self.x_proj_weight.reshape(1, 2 * c, d), seq)           # both directions in one (batched) GEMM
         if _FUSED_SS2D and seq.is_cuda:
             # the flipped direction is read backwards by the kernel: no flipped copies of seq / x_dbl / ys
             p4 = p.view(B, 2, c, L)
             p_dt, p_b, p_c = torch.split(p4, [R, N, N], dim=2)                   # views; backward = one cat
             dts = torch.matmul(self.dt_projs_weight.unsqueeze(0), p_dt)          # (B, 2, d, L)
-            ys = selective_scan_ext(seq, dts.reshape(B, 2 * d, L), -torch.exp(self.A_logs.float()), p_b,
-                                    p_c, self.Ds.float(), self.dt_projs_bias.float().reshape(-1),
-                                    rev_mask=0b10, u_gshift=1).view(B, 2, d, L)
-            y = ys[:, 0] + ys[:, 1]
+            y = selective_scan_ext(seq, dts.reshape(B, 2 * d, L), -torch.exp(self.A_logs.float()), p_b,
+                                   p_c, self.Ds.float(), self.dt_projs_bias.float().reshape(-1),
+                                   rev_mask=0b10, u_gshift=1, pair_sum=True)     # (B, d, L): forward + reversed direction
             y1, y2 = y.split(HW, dim=-1)
-            y_rgb = self.out_norm1(y1.transpose(1, 2).reshape(B, H, W, d))
-            y_e = self.out_norm2(y2.transpose(1, 2).reshape(B, H, W, d))
+            y_rgb = self.out_norm1(transpose_rows(y1).view(B, H, W, d))
+            y_e = self.out_norm2(transpose_rows(y2).view(B, H, W, d))
             return y_rgb, y_e
         x_dbl = torch.stack([p[:, :c], p[:, c:].flip(-1)], dim=1)                # (B, 2, c, L)
         dts, Bs, Cs = torch.split(x_dbl, [R, N, N], dim=2)
@@ -501,8 +515,8 @@ class ConMB_SS2D(nn.Module):
         return y_rgb, y_e
 
     def forward(self, x_rgb: torch.Tensor, x_e: torch.Tensor) -> torch.Tensor:   # (B, H, W, C) each
-        p_rgb = self.in_proj(x_rgb).permute(0, 3, 1, 2).contiguous()             # (B, d, H, W)
-        p_e = self.in_proj_modalx(x_e).permute(0, 3, 1, 2).contiguous()
+        p_rgb = channels_first(self.in_proj(x_rgb))                              # (B, d, H, W)
+        p_e = channels_first(self.in_proj_modalx(x_e))
         y_rgb, y_e = self._scan(_conv_act(self.conv2d, self.act, p_rgb), _conv_act(self.conv2d_modalx, self.act, p_e))
         # squeeze/excite: each modality is gated by the OTHER modality's pooled in_proj output (:1271-1281)
         g_rgb = self.fc1(p_rgb.mean(dim=(2, 3)))                                 # (B, d)

@@ -208,7 +208,7 @@ class SelectiveScanExtFn(torch.autograd.Function):
     directions are the concatenated RGB|X sequence and its flip (vmamba.py:123-163, 369-430)."""
 
     @staticmethod
-    def forward(ctx, u, delta, A, B, C, D, delta_bias, rev_mask, u_gshift):
+    def forward(ctx, u, delta, A, B, C, D, delta_bias, rev_mask, u_gshift, pair_sum=False):
         u, delta = u.float().contiguous(), delta.float().contiguous()
         B = B.float() if B.stride(-1) == 1 else B.float().contiguous()
         C = C.float() if C.stride(-1) == 1 else C.float().contiguous()
@@ -217,27 +217,40 @@ class SelectiveScanExtFn(torch.autograd.Function):
         out, ck = _core.fwd_ext(u, delta, A, B, C, D, delta_bias, True, rev_mask=rev_mask, u_gshift=u_gshift,
                                 need_x=any(ctx.needs_input_grad), ckpt_pitch=pitch)
         ctx.save_for_backward(u, delta, A, B, C, D, delta_bias, ck)
-        ctx.ext = (int(rev_mask), int(u_gshift))
+        ctx.ext = (int(rev_mask), int(u_gshift), bool(pair_sum))
         ctx.pitch = pitch                                     # the backward tile IS the forward's checkpoint pitch
+        if pair_sum:
+            # y = group 0 + group 1 (ConMB's CrossMerge, vmamba.py:151-157).  Summed HERE so that the backward hands the
+            # ONE gradient to both groups through dout_group_shift instead of autograd's two zero-filled (B, 2, d, L)
+            # buffers, two strided copies and an add (SelectBackward0: 1.0 ms per step)
+            Bsz, dim, L = out.shape
+            if B.shape[1] != 2:
+                raise RuntimeError("pair_sum: two groups only")
+            o4 = out.view(Bsz, 2, dim // 2, L)
+            return o4[:, 0] + o4[:, 1]
         return out
 
     @staticmethod
     def backward(ctx, dout):
         u, delta, A, B, C, D, delta_bias, ck = ctx.saved_tensors
-        rev_mask, sh = ctx.ext
-        du, ddelta, dA, dB, dC, dD, dbias = _core.bwd_ext(u, delta, A, B, C, D, delta_bias, dout.float().contiguous(), ck,
-                                                          True, rev_mask=rev_mask, u_gshift=sh, ckpt_pitch=ctx.pitch)
+        rev_mask, sh, pair_sum = ctx.ext
+        dout = dout.float()
+        if dout.stride(-1) != 1:
+            dout = dout.contiguous()
+        du, ddelta, dA, dB, dC, dD, dbias = _core.bwd_ext(u, delta, A, B, C, D, delta_bias, dout, ck,
+                                                          True, rev_mask=rev_mask, u_gshift=sh, dout_gshift=1 if pair_sum else 0,
+                                                          ckpt_pitch=ctx.pitch)
         if sh:
             Bsz, dim, L = du.shape
             G = B.shape[1]
             rpg = dim // G
             du = du.view(Bsz, G >> sh, 1 << sh, rpg, L).sum(2).reshape(Bsz, dim >> sh, L)
         # dA / dD / dbias are views of ONE zero-filled buffer (bwd_ext): hand autograd tensors that own their storage
-        return du, ddelta, dA.clone(), dB, dC, dD.clone(), dbias.clone(), None, None
+        return du, ddelta, dA.clone(), dB, dC, dD.clone(), dbias.clone(), None, None, None
 
 
-def selective_scan_ext(u, delta, A, B, C, D, delta_bias, rev_mask=0, u_gshift=0):
-    return SelectiveScanExtFn.apply(u, delta, A, B, C, D, delta_bias, rev_mask, u_gshift)
+def selective_scan_ext(u, delta, A, B, C, D, delta_bias, rev_mask=0, u_gshift=0, pair_sum=False):
+    return SelectiveScanExtFn.apply(u, delta, A, B, C, D, delta_bias, rev_mask, u_gshift, pair_sum)
 
 
 def _merge_params(B, d, H, W):

@@ -1,0 +1,113 @@
+"""GPU parity of csrc/pointwise.hip (ChannelAttention gate, softmax cross entropy) and of the tiled-transpose layout
+changes (sigma_amd/layout.py) against the torch formulations of the reference -- run with -m gpu."""
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref_gate(x, w1, w2):
+    """ChannelAttention.forward of the reference (vmamba.py:1725-1741) with plain torch ops"""
+    pooled = torch.cat([x.mean(dim=(2, 3), keepdim=True), x.amax(dim=(2, 3), keepdim=True)], dim=0)
+    g = F.conv2d(F.silu(F.conv2d(pooled, w1)), w2)
+    return x * torch.sigmoid(g[:x.shape[0]] + g[x.shape[0]:])
+
+
+@pytest.mark.parametrize("shape,sq", [((2, 96, 30, 40), 30), ((1, 60, 7, 9), 30), ((3, 32, 1, 1), 16), ((2, 192, 15, 20), 30),
+                                      ((1, 96, 120, 160), 30)])
+def test_channel_gate_matches_torch(shape, sq):
+    from sigma_amd.pointwise import channel_gate
+    B, C, H, W = shape
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(shape, generator=g).cuda()
+    w1 = (torch.randn(max(C // sq, 1), C, 1, 1, generator=g) * 0.3).cuda()
+    w2 = (torch.randn(C, max(C // sq, 1), 1, 1, generator=g) * 0.3).cuda()
+    gy = torch.randn(shape, generator=g).cuda()
+    outs = []
+    for fn in (channel_gate, _ref_gate):
+        a, b1, b2 = x.clone().requires_grad_(), w1.clone().requires_grad_(), w2.clone().requires_grad_()
+        y = fn(a, b1, b2)
+        y.backward(gy)
+        outs.append((y.detach(), a.grad, b1.grad, b2.grad))
+    for got, want, name in zip(outs[0], outs[1], ("y", "dx", "dw1", "dw2")):
+        torch.testing.assert_close(got, want, rtol=2e-5, atol=2e-5 * float(want.abs().max()) + 1e-7, msg=lambda m, n=name: f"{n}: {m}")
+
+
+def test_channel_gate_shares_the_max_gradient_between_ties():
+    """torch.amax semantics: tied maxima share the gradient of the pooled maximum"""
+    from sigma_amd.pointwise import channel_gate
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(1, 32, 6, 8, generator=g)
+    x[0, 3, 1, 2] = x[0, 3, 4, 5] = 9.0                       # two maxima in plane 3
+    x[0, 7].fill_(0.25)                                       # a constant plane: 48 ties
+    x = x.cuda()
+    w1 = (torch.randn(2, 32, 1, 1, generator=g) * 0.3).cuda()
+    w2 = (torch.randn(32, 2, 1, 1, generator=g) * 0.3).cuda()
+    gy = torch.randn(1, 32, 6, 8, generator=g).cuda()
+    grads = []
+    for fn in (channel_gate, _ref_gate):
+        a = x.clone().requires_grad_()
+        fn(a, w1, w2).backward(gy)
+        grads.append(a.grad)
+    torch.testing.assert_close(grads[0], grads[1], rtol=2e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("rows_shape,nc", [((2, 30, 40), 40), ((1, 7, 9), 12), ((8, 480, 640), 40), ((1, 1, 3), 4)])
+def test_softmax_cross_entropy_matches_torch(rows_shape, nc):
+    from sigma_amd.pointwise import cross_entropy
+    B, H, W = rows_shape
+    g = torch.Generator().manual_seed(7)
+    nhwc = (torch.randn(B, H, W, nc, generator=g) * 3).cuda()
+    label = torch.randint(0, nc, (B, H, W), generator=g)
+    label[torch.rand(B, H, W, generator=g) < 0.1] = 255
+    label = label.cuda()
+    crit = nn.CrossEntropyLoss(reduction="mean", ignore_index=255)
+    a = nhwc.clone().requires_grad_()
+    loss = cross_entropy(crit, a.permute(0, 3, 1, 2), label)
+    assert loss is not None
+    (loss * 1.7).backward()
+    b = nhwc.clone().requires_grad_()
+    want = crit(b.permute(0, 3, 1, 2), label)
+    (want * 1.7).backward()
+    torch.testing.assert_close(loss, want, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(a.grad, b.grad, rtol=1e-4, atol=1e-6 * float(b.grad.abs().max()) + 1e-12)
+    # run-to-run identical (fixed partial layout, no atomics)
+    again = cross_entropy(crit, nhwc.permute(0, 3, 1, 2), label)
+    assert torch.equal(again, loss.detach())
+
+
+def test_softmax_cross_entropy_declines_what_it_does_not_take():
+    from sigma_amd.pointwise import cross_entropy
+    x = torch.randn(1, 6, 6, 12).cuda()
+    lab = torch.zeros(1, 6, 6, dtype=torch.long).cuda()
+    assert cross_entropy(nn.CrossEntropyLoss(reduction="none"), x.permute(0, 3, 1, 2), lab) is None
+    assert cross_entropy(nn.CrossEntropyLoss(), x.permute(0, 3, 1, 2).contiguous(), lab) is None       # NCHW logits
+    assert cross_entropy(nn.CrossEntropyLoss(), torch.randn(1, 6, 6, 9).cuda().permute(0, 3, 1, 2), lab) is None   # 9 classes
+
+
+@pytest.mark.parametrize("shape", [(2, 30, 40, 96), (1, 7, 9, 20), (3, 1, 5, 4), (2, 120, 160, 192)])
+def test_tiled_layout_changes_match_permute(shape):
+    from sigma_amd.layout import channels_first, channels_last, transpose_rows
+    B, H, W, C = shape
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(shape, generator=g).cuda()
+    gy = torch.randn(B, C, H, W, generator=g).cuda()
+    a = x.clone().requires_grad_()
+    y = channels_first(a)
+    assert y.is_contiguous() and torch.equal(y, x.permute(0, 3, 1, 2))
+    y.backward(gy)
+    assert torch.equal(a.grad, gy.permute(0, 2, 3, 1))
+    b = y.detach().clone().requires_grad_()
+    z = channels_last(b)
+    assert z.is_contiguous() and torch.equal(z, x)
+    z.backward(x)
+    assert torch.equal(b.grad, x.permute(0, 3, 1, 2))
+    # one half of a longer sequence (ConMB: the RGB and the X tokens of the concatenated scan), gradient of a transposed view
+    seq = torch.randn(B, C, 2 * H * W, generator=g).cuda().requires_grad_()
+    h1, h2 = seq.split(H * W, dim=-1)
+    t = transpose_rows(h2)
+    assert t.is_contiguous() and torch.equal(t, h2.transpose(1, 2))
+    t.backward(torch.ones_like(t).transpose(1, 2).contiguous().transpose(1, 2))
+    assert torch.equal(seq.grad[..., H * W:], torch.ones(B, C, H * W).cuda()) and float(seq.grad[..., :H * W].abs().max()) == 0.0
