@@ -44,7 +44,8 @@ typedef struct sigma_dwconv_params {
                               image in column-major order (index w*H + h)                          */
     /* backward */
     const float *g2;       /* (B, n_orders, d, H*W) gradient of out2                                      */
-    float *gpre;           /* (B, d, H, W) scratch: gradient w.r.t. the pre-activation            */
+    float *gpre;           /* (B, d, H, W) scratch: gradient w.r.t. the pre-activation (planes that fit
+                              LDS keep it there: then not written)                                  */
     float *dweight;        /* (d, 1, 3, 3) ACCUMULATED into (caller zeroes)                        */
     float *dbias;          /* (d) ACCUMULATED into, or NULL                                        */
     float *dx;             /* (B, d, H, W) fully written                                           */
@@ -181,14 +182,19 @@ typedef struct sigma_layernorm_params {
     float *workspace;      /* bwd scratch                     */
     /* optional fused gate of SS2D.forward (vmamba.py:1077: y = out_norm(y) * act(z)):
      * y = LayerNorm(x) * silu(gate);  gate rows are gate_row_stride floats apart (z is the second
-     * half of the in_proj output), dgate is contiguous (rows, C).  NULL gate = plain LayerNorm.  */
+     * half of the in_proj output); dgate rows are dgate_row_stride floats apart (0 = C, contiguous):
+     * the caller can have dz written straight into the z half of the in_proj output's gradient.
+     * NULL gate = plain LayerNorm.  */
     const float *gate;
     int64_t gate_row_stride;
     float *dgate;
+    int64_t dgate_row_stride;
 } sigma_layernorm_params;
 
 int sigma_layernorm_fwd(const sigma_layernorm_params *params, void *stream);
 int sigma_layernorm_bwd(const sigma_layernorm_params *params, void *stream);
+/* rows of 2 * C floats the backward needs in `workspace`: one partial (dgamma, dbeta) row per WORKGROUP (its four waves
+ * meet in LDS), added up in a fixed order by a second small kernel */
 int sigma_layernorm_bwd_partial_rows(int64_t rows, int32_t channels);
 
 #ifdef __cplusplus

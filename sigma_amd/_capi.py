@@ -105,6 +105,7 @@ class LayerNormParams(ctypes.Structure):
         ("dy", ctypes.c_void_p), ("dx", ctypes.c_void_p), ("dgamma", ctypes.c_void_p), ("dbeta", ctypes.c_void_p),
         ("workspace", ctypes.c_void_p),
         ("gate", ctypes.c_void_p), ("gate_row_stride", ctypes.c_int64), ("dgate", ctypes.c_void_p),
+        ("dgate_row_stride", ctypes.c_int64),
     ]
 
 

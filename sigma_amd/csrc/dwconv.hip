@@ -62,8 +62,9 @@ __global__ void __launch_bounds__(256) dwconv_silu_fwd_kernel(const DwArgs a) {
     const int H = a.H, W = a.W;
     const long L = (long)H * W;
     const int tw = (W + kTile - 1) / kTile, th = (H + kTile - 1) / kTile;
-    const int plane_id = blockIdx.x / (tw * th);           // b * d + c
-    const int tile_id = blockIdx.x - plane_id * (tw * th);
+    const int lbk = xcd_logical_block((int)blockIdx.x, (int)gridDim.x);   // tiles of a plane share lines: same XCD (L2)
+    const int plane_id = lbk / (tw * th);           // b * d + c
+    const int tile_id = lbk - plane_id * (tw * th);
     const int c = plane_id % a.d;
     const int b = plane_id / a.d;
     const int w0 = (tile_id % tw) * kTile, h0 = (tile_id / tw) * kTile;
@@ -107,8 +108,9 @@ __global__ void __launch_bounds__(256) dwconv_silu_bwd1_kernel(const DwArgs a) {
     const int H = a.H, W = a.W;
     const long L = (long)H * W;
     const int tw = (W + kTile - 1) / kTile, th = (H + kTile - 1) / kTile;
-    const int plane_id = blockIdx.x / (tw * th);
-    const int tile_id = blockIdx.x - plane_id * (tw * th);
+    const int lbk = xcd_logical_block((int)blockIdx.x, (int)gridDim.x);
+    const int plane_id = lbk / (tw * th);
+    const int tile_id = lbk - plane_id * (tw * th);
     const int c = plane_id % a.d;
     const int b = plane_id / a.d;
     const int w0 = (tile_id % tw) * kTile, h0 = (tile_id / tw) * kTile;
@@ -173,8 +175,9 @@ __global__ void __launch_bounds__(256) dwconv_bwd2_kernel(const DwArgs a) {
     const int H = a.H, W = a.W;
     const long L = (long)H * W;
     const int tw = (W + kTile - 1) / kTile, th = (H + kTile - 1) / kTile;
-    const int plane_id = blockIdx.x / (tw * th);
-    const int tile_id = blockIdx.x - plane_id * (tw * th);
+    const int lbk = xcd_logical_block((int)blockIdx.x, (int)gridDim.x);
+    const int plane_id = lbk / (tw * th);
+    const int tile_id = lbk - plane_id * (tw * th);
     const int c = plane_id % a.d;
     const int w0 = (tile_id % tw) * kTile, h0 = (tile_id / tw) * kTile;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -196,6 +199,148 @@ __global__ void __launch_bounds__(256) dwconv_bwd2_kernel(const DwArgs a) {
             dx[(long)h * W + w] = acc;
         }
     }
+}
+
+// ---- whole-plane variants --------------------------------------------------------------------------------------------
+// Planes that fit LDS (everything below the 120 x 160 first stage): ONE workgroup owns a whole (batch, channel) plane.
+// The 32 x 32 tiles above leave 41 % of their lanes idle on a 30 x 40 plane (two tiles, the second 8 columns wide) and fetch
+// every tap with its own 4-byte global load; here the plane is read once with 16-byte loads into a zero-bordered LDS image,
+// taps are LDS reads, and the backward keeps the pre-activation gradient in LDS between its two stencils (no gpre round
+// trip through HBM, one launch instead of two).  Row pitch odd: walking down a column (the column-major order of the
+// scan) touches every bank once.
+__device__ __forceinline__ int plane_pitch(int W) { return (W + 2) | 1; }
+
+__global__ void __launch_bounds__(256) dwconv_silu_fwd_plane_kernel(const DwArgs a) {
+    extern __shared__ float smem[];
+    const int H = a.H, W = a.W, L = H * W, pitch = plane_pitch(W);
+    float* __restrict__ sIn = smem;                       // (H + 2) x pitch, zero border
+    float* __restrict__ sOut = smem + (H + 2) * pitch;    // H x pitch
+    const int plane_id = blockIdx.x;
+    const int c = plane_id % a.d, b = plane_id / a.d;
+    const int tid = threadIdx.x;
+    const float* __restrict__ plane = a.x + (long)plane_id * L;
+    float* __restrict__ o_rm = a.out2 + ((long)(b * a.orders + 0) * a.d + c) * L;
+    float* __restrict__ o_cm = a.out2 + ((long)(b * a.orders + 1) * a.d + c) * L;
+    for (int i = tid; i < (H + 2) * pitch; i += 256) sIn[i] = 0.0f;
+    __syncthreads();
+    if ((W & 3) == 0 && (reinterpret_cast<uintptr_t>(plane) & 15u) == 0) {
+        for (int i4 = tid; i4 < (L >> 2); i4 += 256) {
+            const float4 v = reinterpret_cast<const float4*>(plane)[i4];
+            const int idx = i4 << 2, h = idx / W, w = idx - h * W;
+            float* __restrict__ o = sIn + (h + 1) * pitch + (w + 1);
+            o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+        }
+    } else {
+        for (int idx = tid; idx < L; idx += 256) { const int h = idx / W, w = idx - h * W; sIn[(h + 1) * pitch + (w + 1)] = plane[idx]; }
+    }
+    __syncthreads();
+    float wk[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) wk[i] = a.w[c * 9 + i];
+    const float bias = a.bias ? a.bias[c] : 0.0f;
+    for (int idx = tid; idx < L; idx += 256) {
+        const int h = idx / W, w = idx - h * W;
+        const float* __restrict__ p = sIn + h * pitch + w;             // tap (h - 1, w - 1)
+        float acc = bias;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) acc = fmaf(wk[dy * 3 + dx], p[dy * pitch + dx], acc);
+        const float y = acc * sigmoidf_fast(acc);
+        o_rm[idx] = y;
+        sOut[h * pitch + w] = y;
+    }
+    if (a.orders < 2) return;
+    __syncthreads();
+    for (int idx = tid; idx < L; idx += 256) { const int w = idx / H, h = idx - w * H; o_cm[idx] = sOut[h * pitch + w]; }
+}
+
+__global__ void __launch_bounds__(256) dwconv_silu_bwd_plane_kernel(const DwArgs a) {
+    extern __shared__ float smem[];
+    __shared__ float red[4][10];
+    const int H = a.H, W = a.W, L = H * W, pitch = plane_pitch(W);
+    float* __restrict__ sIn = smem;                       // x, zero border
+    float* __restrict__ sG = smem + (H + 2) * pitch;      // column-major gradient, then gpre; zero border
+    const int plane_id = blockIdx.x;
+    const int c = plane_id % a.d, b = plane_id / a.d;
+    const int tid = threadIdx.x;
+    const float* __restrict__ plane = a.x + (long)plane_id * L;
+    const float* __restrict__ g_rm = a.g2 + ((long)(b * a.orders + 0) * a.d + c) * L;
+    const float* __restrict__ g_cm = a.g2 + ((long)(b * a.orders + 1) * a.d + c) * L;
+    float* __restrict__ dx = a.dx + (long)plane_id * L;
+    for (int i = tid; i < 2 * (H + 2) * pitch; i += 256) smem[i] = 0.0f;
+    __syncthreads();
+    if ((W & 3) == 0 && (reinterpret_cast<uintptr_t>(plane) & 15u) == 0) {
+        for (int i4 = tid; i4 < (L >> 2); i4 += 256) {
+            const float4 v = reinterpret_cast<const float4*>(plane)[i4];
+            const int idx = i4 << 2, h = idx / W, w = idx - h * W;
+            float* __restrict__ o = sIn + (h + 1) * pitch + (w + 1);
+            o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+        }
+    } else {
+        for (int idx = tid; idx < L; idx += 256) { const int h = idx / W, w = idx - h * W; sIn[(h + 1) * pitch + (w + 1)] = plane[idx]; }
+    }
+    if (a.orders > 1)
+        for (int idx = tid; idx < L; idx += 256) { const int w = idx / H, h = idx - w * H; sG[(h + 1) * pitch + (w + 1)] = g_cm[idx]; }
+    __syncthreads();
+    float wk[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) wk[i] = a.w[c * 9 + i];
+    const float bias = a.bias ? a.bias[c] : 0.0f;
+    float acc_w[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    float acc_b = 0.0f;
+    for (int idx = tid; idx < L; idx += 256) {
+        const int h = idx / W, w = idx - h * W;
+        const float* __restrict__ p = sIn + h * pitch + w;
+        float t[9];
+        float pre = bias;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx_ = 0; dx_ < 3; ++dx_) { t[dy * 3 + dx_] = p[dy * pitch + dx_]; pre = fmaf(wk[dy * 3 + dx_], t[dy * 3 + dx_], pre); }
+        const float sg = sigmoidf_fast(pre);
+        const float dsilu = sg * fmaf(pre, 1.0f - sg, 1.0f);
+        float* __restrict__ own = sG + (h + 1) * pitch + (w + 1);       // read and written by this thread only
+        const float g = (g_rm[idx] + *own) * dsilu;
+        *own = g;
+        acc_b += g;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) acc_w[k] = fmaf(g, t[k], acc_w[k]);
+    }
+    __syncthreads();
+    for (int idx = tid; idx < L; idx += 256) {
+        const int h = idx / W, w = idx - h * W;
+        const float* __restrict__ q = sG + h * pitch + w;              // gpre[h - 1][w - 1]
+        float acc = 0.0f;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx_ = 0; dx_ < 3; ++dx_) acc = fmaf(wk[8 - (dy * 3 + dx_)], q[dy * pitch + dx_], acc);
+        dx[idx] = acc;
+    }
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const float s = wave_sum_shfl(acc_w[k]);
+        if (lane == 0) red[wave][k] = s;
+    }
+    {
+        const float s = wave_sum_shfl(acc_b);
+        if (lane == 0) red[wave][9] = s;
+    }
+    __syncthreads();
+    if (tid < 10) {
+        const float s = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+        if (tid < 9) atomicAdd(a.dw + c * 9 + tid, s);
+        else if (a.dbias) atomicAdd(a.dbias + c, s);
+    }
+}
+
+// LDS bytes of the whole-plane kernels (two (H + 2) x pitch images), 0 = the plane does not fit: tiled kernels
+size_t plane_lds_bytes(const sigma_dwconv_params* p) {
+    const long pitch = (p->width + 2) | 1;
+    const long bytes = 2L * (p->height + 2) * pitch * (long)sizeof(float);
+    return bytes <= 48 * 1024 ? (size_t)bytes : 0;
 }
 
 int check(const sigma_dwconv_params* p) {
@@ -226,7 +371,11 @@ int sigma_dwconv3x3_silu_fwd(const sigma_dwconv_params* p, void* stream) {
     sigma::DwArgs a{};
     a.x = p->x; a.w = p->weight; a.bias = p->bias; a.out2 = p->out2;
     a.B = p->batch; a.d = p->channels; a.H = p->height; a.W = p->width; a.orders = p->n_orders;
-    hipLaunchKernelGGL(sigma::dwconv_silu_fwd_kernel, sigma::grid_for(p), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+    if (const size_t lds = sigma::plane_lds_bytes(p))
+        hipLaunchKernelGGL(sigma::dwconv_silu_fwd_plane_kernel, dim3((unsigned)(p->batch * p->channels)), dim3(256), lds,
+                           static_cast<hipStream_t>(stream), a);
+    else
+        hipLaunchKernelGGL(sigma::dwconv_silu_fwd_kernel, sigma::grid_for(p), dim3(256), 0, static_cast<hipStream_t>(stream), a);
     return hipGetLastError() == hipSuccess ? SIGMA_OPS_OK : SIGMA_OPS_ERR_LAUNCH;
 }
 
@@ -240,6 +389,10 @@ int sigma_dwconv3x3_silu_bwd(const sigma_dwconv_params* p, void* stream) {
     a.dw = p->dweight; a.dbias = p->dbias; a.dx = p->dx;
     a.B = p->batch; a.d = p->channels; a.H = p->height; a.W = p->width; a.orders = p->n_orders;
     hipStream_t s = static_cast<hipStream_t>(stream);
+    if (const size_t lds = sigma::plane_lds_bytes(p)) {      // one launch, gpre stays in LDS (p->gpre is not written)
+        hipLaunchKernelGGL(sigma::dwconv_silu_bwd_plane_kernel, dim3((unsigned)(p->batch * p->channels)), dim3(256), lds, s, a);
+        return hipGetLastError() == hipSuccess ? SIGMA_OPS_OK : SIGMA_OPS_ERR_LAUNCH;
+    }
     hipLaunchKernelGGL(sigma::dwconv_silu_bwd1_kernel, sigma::grid_for(p), dim3(256), 0, s, a);
     if (hipGetLastError() != hipSuccess) return SIGMA_OPS_ERR_LAUNCH;
     hipLaunchKernelGGL(sigma::dwconv_bwd2_kernel, sigma::grid_for(p), dim3(256), 0, s, a);

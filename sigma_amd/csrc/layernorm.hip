@@ -30,7 +30,7 @@ __device__ __forceinline__ float wave_allsum(float v) { return wave_sum(v); }
 struct LnArgs {
     const float* x; const float* gamma; const float* beta; const float* dy;
     float* y; float* mean; float* rstd; float* dx; float* ws;   // ws: [nwaves][2][C]
-    const float* z; float* dz; long z_stride;                     // optional SiLU gate: y = LN(x) * silu(z)
+    const float* z; float* dz; long z_stride, dz_stride;          // optional SiLU gate: y = LN(x) * silu(z)
     long M; int C; float eps;
 };
 
@@ -135,7 +135,7 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const LnArgs a) {
                     dzv.y = gv.y * fmaf(xh[j].y, g[j].y, bv.y) * s1_ * fmaf(zv.y, 1.0f - s1_, 1.0f);
                     dzv.z = gv.z * fmaf(xh[j].z, g[j].z, bv.z) * s2_ * fmaf(zv.z, 1.0f - s2_, 1.0f);
                     dzv.w = gv.w * fmaf(xh[j].w, g[j].w, bv.w) * s3 * fmaf(zv.w, 1.0f - s3, 1.0f);
-                    *reinterpret_cast<float4*>(a.dz + r * C + c) = dzv;
+                    *reinterpret_cast<float4*>(a.dz + r * a.dz_stride + c) = dzv;
                     gv.x *= zv.x * s0; gv.y *= zv.y * s1_; gv.z *= zv.z * s2_; gv.w *= zv.w * s3;
                 }
                 t[j] = make_float4(gv.x * g[j].x, gv.y * g[j].y, gv.z * g[j].z, gv.w * g[j].w);
@@ -163,15 +163,25 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const LnArgs a) {
             }
         }
     }
-    float* __restrict__ wg = a.ws + (wave * 2 + 0) * (long)C;
-    float* __restrict__ wb = a.ws + (wave * 2 + 1) * (long)C;
+    // the four waves of the workgroup meet in LDS: ONE partial (dgamma, dbeta) row per workgroup for ln_reduce_kernel
+    // (a row per wave was 4x the partial traffic and made the 48-96 workgroups of the reduction 20 us long)
+    extern __shared__ float part[];                           // [4][2][C]
+    const int wv = threadIdx.x >> 6;
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
         const int c = lane * 4 + 256 * j;
         if (c < C) {
-            *reinterpret_cast<float4*>(wg + c) = dg[j];
-            *reinterpret_cast<float4*>(wb + c) = db[j];
+            *reinterpret_cast<float4*>(part + (wv * 2 + 0) * C + c) = dg[j];
+            *reinterpret_cast<float4*>(part + (wv * 2 + 1) * C + c) = db[j];
         }
+    }
+    __syncthreads();
+    float* __restrict__ wrow = a.ws + (long)blockIdx.x * 2 * C;
+    for (int i = threadIdx.x * 4; i < 2 * C; i += 1024) {
+        const float4 p0 = *reinterpret_cast<const float4*>(part + i), p1 = *reinterpret_cast<const float4*>(part + 2 * C + i);
+        const float4 p2 = *reinterpret_cast<const float4*>(part + 4 * C + i), p3 = *reinterpret_cast<const float4*>(part + 6 * C + i);
+        *reinterpret_cast<float4*>(wrow + i) = make_float4((p0.x + p1.x) + (p2.x + p3.x), (p0.y + p1.y) + (p2.y + p3.y),
+                                                          (p0.z + p1.z) + (p2.z + p3.z), (p0.w + p1.w) + (p2.w + p3.w));
     }
 }
 
@@ -229,10 +239,10 @@ int grid_blocks(long M, long cap = 2048) {   // 2048 blocks = 8192 waves: 8 per 
     if (b < 1) b = 1;
     return (int)b;
 }
-constexpr long kBwdBlocks = 512;             // floor: one partial dgamma/dbeta row per wave, 2048 rows to add
-// waves of the backward: up to 8 per SIMD while the partial rows (2 x C floats per wave) stay within 8 MB
+constexpr long kBwdBlocks = 512;             // floor: 2048 waves
+// workgroups of the backward: up to 8 waves per SIMD while the partial rows (2 x C floats per workgroup) stay within 2 MB
 long bwd_blocks(long rows, int C) {
-    long cap = (8L << 20) / (8L * C) / 4;    // workgroups of 4 waves
+    long cap = (2L << 20) / (8L * C);
     if (cap > 2048) cap = 2048;
     if (cap < kBwdBlocks) cap = kBwdBlocks;
     return cap;
@@ -249,7 +259,7 @@ bool check(const sigma_layernorm_params* p) {
 extern "C" {
 
 int sigma_layernorm_bwd_partial_rows(int64_t rows, int32_t channels) {
-    return sigma::grid_blocks(rows, sigma::bwd_blocks(rows, channels > 0 ? channels : 4)) * 4;
+    return sigma::grid_blocks(rows, sigma::bwd_blocks(rows, channels > 0 ? channels : 4));
 }
 
 int sigma_layernorm_fwd(const sigma_layernorm_params* p, void* stream) {
@@ -280,15 +290,18 @@ int sigma_layernorm_bwd(const sigma_layernorm_params* p, void* stream) {
         sigma::LnArgs a{};
         a.x = p->x; a.gamma = p->gamma; a.beta = p->beta; a.dy = p->dy; a.mean = p->mean; a.rstd = p->rstd; a.dx = p->dx;
         a.ws = p->workspace; a.z = p->gate; a.z_stride = p->gate_row_stride; a.dz = p->dgate;
-        if (p->gate && (!p->dgate || p->gate_row_stride % 4 != 0 || p->gate_row_stride < p->channels)) return SIGMA_OPS_ERR_ARG;
+        a.dz_stride = p->dgate_row_stride > 0 ? p->dgate_row_stride : p->channels;
+        if (p->gate && (!p->dgate || p->gate_row_stride % 4 != 0 || p->gate_row_stride < p->channels || a.dz_stride % 4 != 0 ||
+                        a.dz_stride < p->channels))
+            return SIGMA_OPS_ERR_ARG;
         a.M = p->rows; a.C = p->channels; a.eps = p->eps;
         const bool ok = sigma::dispatch_nv(p->channels, [&](auto nv) {
-            hipLaunchKernelGGL(sigma::ln_bwd_kernel<decltype(nv)::value>, dim3(grid), dim3(256), 0, s, a);
+            hipLaunchKernelGGL(sigma::ln_bwd_kernel<decltype(nv)::value>, dim3(grid), dim3(256), 8 * p->channels * sizeof(float), s, a);
         });
         if (!ok) return SIGMA_OPS_ERR_ARG;
         if (hipGetLastError() != hipSuccess) return SIGMA_OPS_ERR_LAUNCH;
     }
-    const int nw = p->rows > 0 ? grid * 4 : 0;
+    const int nw = p->rows > 0 ? grid : 0;                   // partial rows: one per workgroup
     hipLaunchKernelGGL(sigma::ln_reduce_kernel, dim3((2 * p->channels + 15) / 16), dim3(256), 0, s, p->workspace, p->dgamma,
                        p->dbeta, nw, p->channels);
     return hipGetLastError() == hipSuccess ? SIGMA_OPS_OK : SIGMA_OPS_ERR_LAUNCH;

@@ -16,6 +16,7 @@
 #include <stdint.h>
 
 #include "../../include/sigma_ops.h"
+#include "scan_device.h"
 
 namespace sigma {
 
@@ -42,10 +43,14 @@ __global__ void __launch_bounds__(256) cross_merge_kernel(const MergeArgs a) {
     const int H = a.H, W = a.W, d = a.d;
     const long L = (long)H * W;
     const int tw = (W + kP - 1) / kP, th = (H + kP - 1) / kP, tc = (d + kC - 1) / kC;
-    int bid = blockIdx.x;
-    const int ci = bid % tc; bid /= tc;
+    // The tiles of one (batch, channel block) share cache lines (a tile row is a 64-byte run, half a line; on the small
+    // planes of the late stages a line even spans image rows).  Hardware deals consecutive workgroup ids round-robin to
+    // the 8 XCDs, each with its own L2: neighbouring tiles on different XCDs fetch every shared line twice and cannot
+    // merge their half-line writes.  Logical ids that are consecutive on ONE XCD (scan_device.h), pixel tiles fastest.
+    int bid = xcd_logical_block((int)blockIdx.x, (int)gridDim.x);
     const int wi = bid % tw; bid /= tw;
     const int hi = bid % th; bid /= th;
+    const int ci = bid % tc; bid /= tc;
     const int b = bid;
     const int c0 = ci * kC, w0 = wi * kP, h0 = hi * kP;
     const int tid = threadIdx.x;
@@ -83,10 +88,14 @@ __global__ void __launch_bounds__(256) cross_split_kernel(const MergeArgs a) {
     const int H = a.H, W = a.W, d = a.d;
     const long L = (long)H * W;
     const int tw = (W + kP - 1) / kP, th = (H + kP - 1) / kP, tc = (d + kC - 1) / kC;
-    int bid = blockIdx.x;
-    const int ci = bid % tc; bid /= tc;
+    // The tiles of one (batch, channel block) share cache lines (a tile row is a 64-byte run, half a line; on the small
+    // planes of the late stages a line even spans image rows).  Hardware deals consecutive workgroup ids round-robin to
+    // the 8 XCDs, each with its own L2: neighbouring tiles on different XCDs fetch every shared line twice and cannot
+    // merge their half-line writes.  Logical ids that are consecutive on ONE XCD (scan_device.h), pixel tiles fastest.
+    int bid = xcd_logical_block((int)blockIdx.x, (int)gridDim.x);
     const int wi = bid % tw; bid /= tw;
     const int hi = bid % th; bid /= th;
+    const int ci = bid % tc; bid /= tc;
     const int b = bid;
     const int c0 = ci * kC, w0 = wi * kP, h0 = hi * kP;
     const int tid = threadIdx.x;

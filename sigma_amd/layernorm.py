@@ -60,6 +60,12 @@ class LayerNormFn(torch.autograd.Function):
             ctx.gated = gate is not None
             ctx.gate_shape = None if gate is None else tuple(gate.shape)
             ctx.zstride = zstride if gate is not None else 0
+            # gate = second half of a contiguous (..., 2C) tensor (SS2D: z of the in_proj output): the backward then
+            # writes dz into the z half of ONE (..., 2C) gradient buffer, which SplitXZFn.backward completes in place
+            base = gate._base if gate is not None else None
+            ctx.gate_half = bool(gate is not None and zk is gate and zstride == 2 * C and base is not None and base.is_contiguous()
+                                 and base.shape[-1] == 2 * C and base.numel() == 2 * gate.numel()
+                                 and gate.data_ptr() == base.data_ptr() + 4 * C)
             ctx.eps = float(eps)
         return y
 
@@ -82,7 +88,12 @@ class LayerNormFn(torch.autograd.Function):
         p.dbeta = dbeta.data_ptr() if dbeta is not None else None
         dz = None
         if ctx.gated:
-            dz = torch.empty(ctx.gate_shape, device=xc.device, dtype=torch.float32)
+            if ctx.gate_half:
+                full = torch.empty(*ctx.gate_shape[:-1], 2 * C, device=xc.device, dtype=torch.float32)
+                dz = full[..., C:]
+                p.dgate_row_stride = 2 * C
+            else:
+                dz = torch.empty(ctx.gate_shape, device=xc.device, dtype=torch.float32)
             p.beta = bias.data_ptr() if ctx.has_bias else None
             p.gate, p.gate_row_stride, p.dgate = zk.data_ptr(), ctx.zstride, dz.data_ptr()
         with torch.cuda.device(xc.device):

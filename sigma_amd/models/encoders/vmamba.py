@@ -384,11 +384,14 @@ class Cross_Mamba_Attention_SSM(nn.Module):
 
     def _project(self, x_seq, x_proj, dt_proj):
         """x_seq (B, d, L) -> delta (B, d, L), B (B, N, L), C (B, N, L); bias enters via delta_bias."""
-        # the weights as a broadcast batch: matmul(2-D, 3-D) folds the batch into the rows of ONE GEMM and for that
-        # copies the activations into (B, L, d) order first (2 x 59 MB per call at 120 x 160)
-        dbl = torch.matmul(x_proj.weight.unsqueeze(0), x_seq)        # (B, R+2N, L)
+        # bmm with the weights as a stride-0 batch: torch.matmul folds the batch of a (2-D | 1 x 2-D) @ 3-D product into the
+        # rows of ONE GEMM and for that copies the activations into (B, L, d) order first (2 x 59 MB per call at
+        # 120 x 160, and a transposed gradient to add in backward)
+        Bsz = x_seq.shape[0]
+        dbl = torch.bmm(x_proj.weight.unsqueeze(0).expand(Bsz, -1, -1), x_seq)       # (B, R+2N, L)
         dt, Bm, Cm = torch.split(dbl, [self.dt_rank, self.d_state, self.d_state], dim=1)
-        return torch.matmul(dt_proj.weight.unsqueeze(0), dt), Bm, Cm   # B / C: row slices, read in place by the scan
+        # B / C: row slices of dbl, read in place by the scan
+        return torch.bmm(dt_proj.weight.unsqueeze(0).expand(Bsz, -1, -1), dt), Bm, Cm
 
     def forward(self, x_rgb: torch.Tensor, x_e: torch.Tensor):   # both (B, d, L) channel-major sequences
         dt_rgb, B_rgb, C_rgb = self._project(x_rgb, self.x_proj_1, self.dt_proj_1)
@@ -488,7 +491,8 @@ class ConMB_SS2D(nn.Module):
         R, N = self.dt_rank, self.d_state
         c = R + 2 * N
         seq = torch.cat([c_rgb.flatten(2), c_e.flatten(2)], dim=2)               # (B, d, 2HW): rgb tokens first
-        p = torch.matmul(self.x_proj_weight.reshape(1, 2 * c, d), seq)           # both directions in one (batched) GEMM
+        # both directions in one batched GEMM (bmm, weights as a stride-0 batch: see Cross_Mamba_Attention_SSM._project)
+        p = torch.bmm(self.x_proj_weight.reshape(1, 2 * c, d).expand(B, -1, -1), seq)
         if _FUSED_SS2D and seq.is_cuda:
             # the flipped direction is read backwards by the kernel: no flipped copies of seq / x_dbl / ys
             p4 = p.view(B, 2, c, L)

@@ -188,12 +188,18 @@ class SplitXZFn(torch.autograd.Function):
     def backward(ctx, dx, dz):
         B, H, W, d = ctx.dims
         L = H * W
-        dxz = torch.empty(B, H, W, 2 * d, device=dx.device, dtype=dx.dtype)
-        _transpose2d(dx.contiguous(), dxz, B, d, L, d * L, L, L * 2 * d, 2 * d)
-        if dz is None:
-            dxz[..., d:].zero_()
+        base = dz._base if dz is not None else None
+        if (base is not None and tuple(base.shape) == (B, H, W, 2 * d) and base.is_contiguous() and base.dtype == dx.dtype
+                and tuple(dz.shape) == (B, H, W, d) and dz.data_ptr() == base.data_ptr() + 4 * d and dz.stride(-1) == 1
+                and dz.stride(-2) == 2 * d):
+            dxz = base                    # the gated LayerNorm's backward wrote dz into the z half already (layernorm.py)
         else:
-            dxz[..., d:].copy_(dz)
+            dxz = torch.empty(B, H, W, 2 * d, device=dx.device, dtype=dx.dtype)
+            if dz is None:
+                dxz[..., d:].zero_()
+            else:
+                dxz[..., d:].copy_(dz)
+        _transpose2d(dx.contiguous(), dxz, B, d, L, d * L, L, L * 2 * d, 2 * d)
         return dxz
 
 
