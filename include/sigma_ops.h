@@ -189,6 +189,12 @@ typedef struct sigma_layernorm_params {
     int64_t gate_row_stride;
     float *dgate;
     int64_t dgate_row_stride;
+    /* optional per-sample factor on the OUTPUT (stochastic depth, timm DropPath as used by VSSBlock vmamba.py:1716-1722
+     * and CVSSDecoderBlock :1800-1805: the branch is multiplied by mask[b] / keep_prob before the residual add):
+     * y = (LayerNorm(x) [* silu(gate)]) * row_scale[r / rows_per_scale]; the backward multiplies dy by the same factor
+     * on load.  The out_proj that follows is linear and bias-free, so scaling its input scales the branch.  NULL = 1. */
+    const float *row_scale;
+    int64_t rows_per_scale;
 } sigma_layernorm_params;
 
 int sigma_layernorm_fwd(const sigma_layernorm_params *params, void *stream);

@@ -106,6 +106,7 @@ class LayerNormParams(ctypes.Structure):
         ("workspace", ctypes.c_void_p),
         ("gate", ctypes.c_void_p), ("gate_row_stride", ctypes.c_int64), ("dgate", ctypes.c_void_p),
         ("dgate_row_stride", ctypes.c_int64),
+        ("row_scale", ctypes.c_void_p), ("rows_per_scale", ctypes.c_int64),
     ]
 
 

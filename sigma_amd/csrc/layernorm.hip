@@ -31,6 +31,7 @@ struct LnArgs {
     const float* x; const float* gamma; const float* beta; const float* dy;
     float* y; float* mean; float* rstd; float* dx; float* ws;   // ws: [nwaves][2][C]
     const float* z; float* dz; long z_stride, dz_stride;          // optional SiLU gate: y = LN(x) * silu(z)
+    const float* rsc; long rows_per_scale;                        // optional per-sample output factor (stochastic depth)
     long M; int C; float eps;
 };
 
@@ -52,6 +53,9 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(const LnArgs a) {
         b[j] = (c < C && a.beta) ? *reinterpret_cast<const float4*>(a.beta + c) : make_float4(0, 0, 0, 0);
     }
     const float inv = 1.0f / (float)C;
+    // sample of the row for the per-sample factor: ONE division per wave, then carried along (a 64-bit division per row
+    // cost more than the row itself at C <= 256: 69 -> 106 us on the 153600 x 192 backward)
+    long sb = a.rsc ? wave / a.rows_per_scale : 0, srem = a.rsc ? wave - sb * a.rows_per_scale : 0;
     for (long r = wave; r < a.M; r += nwaves) {
         const float* __restrict__ xr = a.x + r * C;
         float4 v[NV];
@@ -75,6 +79,12 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(const LnArgs a) {
         const float rs = rsqrtf(wave_allsum(q) * inv + a.eps);
         float* __restrict__ yr = a.y + r * C;
         const float* __restrict__ zr = a.z ? a.z + r * a.z_stride : nullptr;
+        float sc = 1.0f;
+        if (a.rsc) {
+            sc = a.rsc[sb];
+            srem += nwaves;
+            while (srem >= a.rows_per_scale) { srem -= a.rows_per_scale; ++sb; }
+        }
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             const int c = lane * 4 + 256 * j;
@@ -89,6 +99,7 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(const LnArgs a) {
                     o.x *= zv.x * sigmoid_f(zv.x); o.y *= zv.y * sigmoid_f(zv.y);
                     o.z *= zv.z * sigmoid_f(zv.z); o.w *= zv.w * sigmoid_f(zv.w);
                 }
+                if (a.rsc) { o.x *= sc; o.y *= sc; o.z *= sc; o.w *= sc; }
                 *reinterpret_cast<float4*>(yr + c) = o;
             }
         }
@@ -112,10 +123,17 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const LnArgs a) {
     }
     const bool gated = a.z != nullptr;
     const float inv = 1.0f / (float)C;
+    long sb = a.rsc ? wave / a.rows_per_scale : 0, srem = a.rsc ? wave - sb * a.rows_per_scale : 0;
     for (long r = wave; r < a.M; r += nwaves) {
         const float* __restrict__ xr = a.x + r * C;
         const float* __restrict__ gr = a.dy + r * C;
         const float mu = a.mean[r], rs = a.rstd[r];
+        float sc = 1.0f;
+        if (a.rsc) {
+            sc = a.rsc[sb];
+            srem += nwaves;
+            while (srem >= a.rows_per_scale) { srem -= a.rows_per_scale; ++sb; }
+        }
         float4 xh[NV], t[NV];
         float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll
@@ -124,6 +142,7 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const LnArgs a) {
             if (c < C) {
                 const float4 xv = *reinterpret_cast<const float4*>(xr + c);
                 float4 gv = *reinterpret_cast<const float4*>(gr + c);
+                if (a.rsc) { gv.x *= sc; gv.y *= sc; gv.z *= sc; gv.w *= sc; }
                 xh[j] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
                 if (gated) {
                     // out = n * silu(z), n = xhat * gamma + beta:  dn = dout * silu(z),  dz = dout * n * silu'(z)
@@ -270,6 +289,8 @@ int sigma_layernorm_fwd(const sigma_layernorm_params* p, void* stream) {
     a.x = p->x; a.gamma = p->gamma; a.beta = p->beta; a.y = p->y; a.mean = p->mean; a.rstd = p->rstd;
     a.z = p->gate; a.z_stride = p->gate_row_stride;
     if (p->gate && (p->gate_row_stride % 4 != 0 || p->gate_row_stride < p->channels)) return SIGMA_OPS_ERR_ARG;
+    a.rsc = p->row_scale; a.rows_per_scale = p->rows_per_scale;
+    if (p->row_scale && p->rows_per_scale <= 0) return SIGMA_OPS_ERR_ARG;
     a.M = p->rows; a.C = p->channels; a.eps = p->eps;
     const int grid = sigma::grid_blocks(p->rows);
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -291,6 +312,8 @@ int sigma_layernorm_bwd(const sigma_layernorm_params* p, void* stream) {
         a.x = p->x; a.gamma = p->gamma; a.beta = p->beta; a.dy = p->dy; a.mean = p->mean; a.rstd = p->rstd; a.dx = p->dx;
         a.ws = p->workspace; a.z = p->gate; a.z_stride = p->gate_row_stride; a.dz = p->dgate;
         a.dz_stride = p->dgate_row_stride > 0 ? p->dgate_row_stride : p->channels;
+        a.rsc = p->row_scale; a.rows_per_scale = p->rows_per_scale;
+        if (p->row_scale && p->rows_per_scale <= 0) return SIGMA_OPS_ERR_ARG;
         if (p->gate && (!p->dgate || p->gate_row_stride % 4 != 0 || p->gate_row_stride < p->channels || a.dz_stride % 4 != 0 ||
                         a.dz_stride < p->channels))
             return SIGMA_OPS_ERR_ARG;

@@ -32,7 +32,7 @@ def _gate_view(z: torch.Tensor, C: int):
 
 class LayerNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, eps, gate=None):
+    def forward(ctx, x, weight, bias, eps, gate=None, row_scale=None):
         lib = _capi.load()
         xc = x.contiguous()
         C = xc.shape[-1]
@@ -50,12 +50,19 @@ class LayerNormFn(torch.autograd.Function):
         if gate is not None:
             zk, zstride = _gate_view(gate, C)
             p.gate, p.gate_row_stride = zk.data_ptr(), zstride
+        rsc = None
+        if row_scale is not None:                 # one factor per sample (leading dimension), see include/sigma_ops.h
+            rsc = row_scale.detach().reshape(-1).float().contiguous()
+            if rsc.numel() == 0 or rows % rsc.numel() != 0 or rsc.numel() != xc.shape[0]:
+                raise RuntimeError("LayerNorm row_scale: one factor per sample of the leading dimension")
+            p.row_scale, p.rows_per_scale = rsc.data_ptr(), rows // rsc.numel()
         with torch.cuda.device(x.device):
             _capi.check(lib.sigma_layernorm_fwd(ctypes.byref(p), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
                         "layernorm_fwd")
         if need_bwd:
             ctx.save_for_backward(xc, weight, mean, rstd, bias if bias is not None else weight.new_empty(0),
-                                  zk if zk is not None else weight.new_empty(0))
+                                  zk if zk is not None else weight.new_empty(0), rsc if rsc is not None else weight.new_empty(0))
+            ctx.scaled = rsc is not None
             ctx.has_bias = bias is not None
             ctx.gated = gate is not None
             ctx.gate_shape = None if gate is None else tuple(gate.shape)
@@ -72,7 +79,7 @@ class LayerNormFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         lib = _capi.load()
-        xc, weight, mean, rstd, bias, zk = ctx.saved_tensors
+        xc, weight, mean, rstd, bias, zk, rsc = ctx.saved_tensors
         C = xc.shape[-1]
         rows = xc.numel() // C
         dy = dy.contiguous()
@@ -86,6 +93,8 @@ class LayerNormFn(torch.autograd.Function):
         p.x, p.gamma, p.mean, p.rstd = xc.data_ptr(), weight.data_ptr(), mean.data_ptr(), rstd.data_ptr()
         p.dy, p.dx, p.dgamma, p.workspace = dy.data_ptr(), dx.data_ptr(), dgamma.data_ptr(), ws.data_ptr()
         p.dbeta = dbeta.data_ptr() if dbeta is not None else None
+        if ctx.scaled:
+            p.row_scale, p.rows_per_scale = rsc.data_ptr(), rows // rsc.numel()
         dz = None
         if ctx.gated:
             if ctx.gate_half:
@@ -99,7 +108,7 @@ class LayerNormFn(torch.autograd.Function):
         with torch.cuda.device(xc.device):
             _capi.check(lib.sigma_layernorm_bwd(ctypes.byref(p), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
                         "layernorm_bwd")
-        return dx, dgamma, dbeta, None, dz
+        return dx, dgamma, dbeta, None, dz, None
 
 
 def _aligned16(*tensors) -> bool:
@@ -120,13 +129,15 @@ class LayerNorm(nn.LayerNorm):
             return LayerNormFn.apply(x, self.weight, self.bias, self.eps)
         return F.layer_norm(x, self.normalized_shape, self.weight, self.bias, self.eps)
 
-    def forward_gated(self, x: torch.Tensor, z: torch.Tensor) -> torch.Tensor:
+    def forward_gated(self, x: torch.Tensor, z: torch.Tensor, row_scale=None) -> torch.Tensor:
         """LayerNorm(x) * silu(z) in one pass (SS2D.forward, vmamba.py:1077); z may be the strided
-        second half of the in_proj output."""
+        second half of the in_proj output.  ``row_scale``: optional per-sample factor on the result (the stochastic-depth
+        mask of the block, applied here for free instead of in a pass of its own after out_proj)."""
         C = x.shape[-1]
         if (x.is_cuda and x.dtype == torch.float32 and z.dtype == torch.float32 and self.elementwise_affine
                 and len(self.normalized_shape) == 1 and C % 4 == 0 and 0 < C <= 2048 and x.numel() > 0
                 and tuple(z.shape) == tuple(x.shape) and _aligned16(self.weight, self.bias)
                 and (not x.is_contiguous() or x.data_ptr() % 16 == 0)):
-            return LayerNormFn.apply(x, self.weight, self.bias, self.eps, z)
-        return self.forward(x) * F.silu(z)
+            return LayerNormFn.apply(x, self.weight, self.bias, self.eps, z, row_scale)
+        y = self.forward(x) * F.silu(z)
+        return y if row_scale is None else y * row_scale.reshape(-1, *([1] * (y.dim() - 1)))

@@ -73,6 +73,17 @@ class DropPath(nn.Module):
             mask.div_(keep)
         return torch.addcmul(residual, x, mask)
 
+    def draw(self, x: torch.Tensor):
+        """the per-sample factor of this call (mask / keep_prob, shape (B, 1, ..., 1)) or None when nothing is dropped --
+        for callers that fold it into the branch (SS2D applies it inside its gated LayerNorm pass)"""
+        if self.drop_prob == 0.0 or not self.training:
+            return None
+        keep = 1.0 - self.drop_prob
+        mask = x.new_empty((x.shape[0],) + (1,) * (x.dim() - 1)).bernoulli_(keep)
+        if keep > 0.0:
+            mask.div_(keep)
+        return mask
+
     def extra_repr(self) -> str:
         return f"drop_prob={self.drop_prob:.3f}"
 
@@ -224,7 +235,10 @@ class SS2D(nn.Module):
         self.out_proj = nn.Linear(self.d_inner, d_model, bias=bias)
         self.dropout = nn.Dropout(dropout) if dropout > 0.0 else nn.Identity()
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:       # x: (B, H, W, C)
+    def forward(self, x: torch.Tensor, branch_scale=None) -> torch.Tensor:       # x: (B, H, W, C)
+        """``branch_scale``: optional per-sample factor (B, 1, 1, 1) on the result -- the block's stochastic-depth mask.
+        out_proj is linear and bias-free, so the factor is applied to its input inside the gated LayerNorm pass."""
+        fold = branch_scale is not None and self.out_proj.bias is None and isinstance(self.dropout, nn.Identity)
         xz = self.in_proj(x)
         if _FUSED_SS2D and _FUSED_SPLIT and xz.is_cuda and xz.dtype == torch.float32:
             xi, z = split_xz(xz)                                             # (B, d, H, W), view (B, H, W, d)
@@ -238,14 +252,18 @@ class SS2D(nn.Module):
             y = ss2d_core_from_orders(xs2, Hq, Wq, self.x_proj_weight, self.dt_projs_weight, self.dt_projs_bias,
                                       self.A_logs, self.Ds)
             if _FUSED_GATE:
-                y = self.out_norm.forward_gated(y, z).to(x.dtype)          # out_norm(y) * silu(z), one pass
+                # out_norm(y) * silu(z) (* mask), one pass
+                y = self.out_norm.forward_gated(y, z, branch_scale if fold else None).to(x.dtype)
             else:
                 y = self.out_norm(y).to(x.dtype) * F.silu(z)
+                fold = False
         else:
             y = ss2d_scan(self.act(self.conv2d(xi)), self.x_proj_weight, self.dt_projs_weight, self.dt_projs_bias,
                           self.A_logs, self.Ds, self.out_norm)
             y = y * F.silu(z)
-        return self.dropout(self.out_proj(y))
+            fold = False
+        out = self.dropout(self.out_proj(y))
+        return out if (branch_scale is None or fold) else out * branch_scale
 
 
 class PatchMerging2D(nn.Module):
@@ -286,7 +304,8 @@ class VSSBlock(nn.Module):
         self.drop_path = DropPath(drop_path)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        return self.drop_path.add_to(x, self.op(self.norm(x)))
+        # x + drop_path(op(norm(x))): the per-sample mask rides inside the branch (SS2D.forward), the residual is one add
+        return x + self.op(self.norm(x), self.drop_path.draw(x))
 
 
 # --------------------------------------------------------------------------- decoder block
@@ -347,7 +366,9 @@ class CVSSDecoderBlock(nn.Module):
         self.scale2 = nn.Parameter(torch.ones(hidden_dim))
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:       # (B, H, W, C)
-        x = self.drop_path.add_to(x * self.scale1, self.op(self.norm1(x)))
+        # x * scale1 + drop_path(op(norm1(x))): mask inside the branch, scale + add in one pass (branch first: the result
+        # inherits its contiguous channels-last layout)
+        x = torch.addcmul(self.op(self.norm1(x), self.drop_path.draw(x)), x, self.scale1)
         y = self.conv_blk(channels_first(self.norm2(x)))
         # the channels-last operand first: the sum then comes out contiguous in (B, H, W, C) and the next block's
         # LayerNorm / in_proj read it in place (with the permuted conv output first, the result inherited its NCHW

@@ -111,3 +111,59 @@ def test_tiled_layout_changes_match_permute(shape):
     assert t.is_contiguous() and torch.equal(t, h2.transpose(1, 2))
     t.backward(torch.ones_like(t).transpose(1, 2).contiguous().transpose(1, 2))
     assert torch.equal(seq.grad[..., H * W:], torch.ones(B, C, H * W).cuda()) and float(seq.grad[..., :H * W].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("shape,gated", [((4, 6, 10, 96), True), ((3, 5, 7, 384), True), ((2, 9, 4, 768), False), ((5, 1, 3, 32), True)])
+def test_layernorm_with_per_sample_factor_matches_torch(shape, gated):
+    """sigma_layernorm_params.row_scale (include/sigma_ops.h): (LayerNorm(x) [* silu(z)]) * mask[b] and its backward, with z
+    the second half of a (..., 2C) tensor whose gradient buffer the backward completes (dgate_row_stride)."""
+    from sigma_amd.layernorm import LayerNorm, LayerNormFn
+    B, H, W, C = shape
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(shape, generator=g).cuda()
+    xz = torch.randn(B, H, W, 2 * C, generator=g).cuda()
+    mask = (torch.rand(B, 1, 1, 1, generator=g) < 0.7).float().div_(0.7).cuda()
+    gy = torch.randn(shape, generator=g).cuda()
+    ln = LayerNorm(C).cuda()
+    with torch.no_grad():
+        ln.weight.copy_(torch.randn(C, generator=g))
+        ln.bias.copy_(torch.randn(C, generator=g))
+    res = []
+    for hip in (True, False):
+        a, b = x.clone().requires_grad_(), xz.clone().requires_grad_()
+        z = b[..., C:]
+        ln.zero_grad()
+        if hip:
+            y = ln.forward_gated(a, z, mask) if gated else LayerNormFn.apply(a, ln.weight, ln.bias, ln.eps, None, mask)
+        else:
+            y = F.layer_norm(a, (C,), ln.weight, ln.bias, ln.eps)
+            y = (y * F.silu(z) if gated else y) * mask
+        y.backward(gy)
+        res.append([y.detach(), a.grad, ln.weight.grad.clone(), ln.bias.grad.clone()] + ([b.grad] if gated else []))
+    for got, want, name in zip(res[0], res[1], ("y", "dx", "dgamma", "dbeta", "dxz")):
+        torch.testing.assert_close(got, want, rtol=2e-5, atol=3e-5 * float(want.abs().max()) + 1e-7, msg=lambda m, n=name: f"{n}: {m}")
+
+
+def test_vss_block_with_stochastic_depth_equals_masked_branch():
+    """VSSBlock in training mode: x + mask[b] / keep * SS2D(LN(x)) (vmamba.py:1716-1722) with the mask folded into the
+    gated LayerNorm pass equals the same branch multiplied after out_proj (same random draw)."""
+    import importlib
+    vm = importlib.import_module("sigma_amd.models.encoders.vmamba")
+    torch.manual_seed(3)
+    blk = vm.VSSBlock(hidden_dim=32, drop_path=0.4, d_state=4).cuda().train()
+    x = torch.randn(6, 8, 12, 32).cuda()
+    gy = torch.randn(6, 8, 12, 32).cuda()
+    outs = []
+    for folded in (True, False):
+        torch.manual_seed(17)
+        a = x.clone().requires_grad_()
+        blk.zero_grad()
+        if folded:
+            y = blk(a)
+        else:
+            mask = blk.drop_path.draw(a)
+            y = a + blk.op(blk.norm(a)) * mask
+        y.backward(gy)
+        outs.append([y.detach(), a.grad] + [p.grad.clone() for p in blk.parameters()])
+    for i, (got, want) in enumerate(zip(outs[0], outs[1])):
+        torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-5 * float(want.abs().max()) + 1e-7, msg=lambda m, i=i: f"tensor {i}: {m}")
