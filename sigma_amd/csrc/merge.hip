@@ -58,20 +58,48 @@ __global__ void __launch_bounds__(256) cross_merge_kernel(const MergeArgs a) {
     const float* __restrict__ p1 = a.ys + ((long)(b * 4 + 1) * d) * L;
     const float* __restrict__ p2 = a.ys + ((long)(b * 4 + 2) * d) * L;
     const float* __restrict__ p3 = a.ys + ((long)(b * 4 + 3) * d) * L;
+    // Loads in batches of kU elements per thread, ALL issued before the first use (unconditional loads from a clamped
+    // address, then a select): with one or two loads in flight per thread the kernel moved 2.4 TB/s -- 16 waves x 2 x 256 B
+    // per CU in flight is ~1 TB/s worth of outstanding bytes at HBM latency.
+    constexpr int kU = 8;
     // row-major planes: consecutive threads -> consecutive w
-    for (int e = tid; e < kC * kP * kP; e += 256) {
-        const int wl = e & (kP - 1), hl = (e >> 4) & (kP - 1), cl = e >> 8;
-        const int c = c0 + cl, h = h0 + hl, w = w0 + wl;
-        float v = 0.0f;
-        if (c < d && h < H && w < W) { const long o = (long)c * L + (long)h * W + w; v = p0[o] + p1[o]; }
-        t[lds_idx(cl, hl, wl)] = v;
+    for (int e0 = tid; e0 < kC * kP * kP; e0 += 256 * kU) {
+        float a0[kU], a1[kU];
+        bool in[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int e = e0 + 256 * u;
+            const int wl = e & (kP - 1), hl = (e >> 4) & (kP - 1), cl = e >> 8;
+            const int c = c0 + cl, h = h0 + hl, w = w0 + wl;
+            in[u] = c < d && h < H && w < W;
+            const long o = in[u] ? (long)c * L + (long)h * W + w : 0;
+            a0[u] = p0[o]; a1[u] = p1[o];
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int e = e0 + 256 * u;
+            t[lds_idx(e >> 8, (e >> 4) & (kP - 1), e & (kP - 1))] = in[u] ? a0[u] + a1[u] : 0.0f;
+        }
     }
     __syncthreads();
     // column-major planes: consecutive threads -> consecutive h
-    for (int e = tid; e < kC * kP * kP; e += 256) {
-        const int hl = e & (kP - 1), wl = (e >> 4) & (kP - 1), cl = e >> 8;
-        const int c = c0 + cl, h = h0 + hl, w = w0 + wl;
-        if (c < d && h < H && w < W) { const long o = (long)c * L + (long)w * H + h; t[lds_idx(cl, hl, wl)] += p2[o] + p3[o]; }
+    for (int e0 = tid; e0 < kC * kP * kP; e0 += 256 * kU) {
+        float a2[kU], a3[kU];
+        bool in[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int e = e0 + 256 * u;
+            const int hl = e & (kP - 1), wl = (e >> 4) & (kP - 1), cl = e >> 8;
+            const int c = c0 + cl, h = h0 + hl, w = w0 + wl;
+            in[u] = c < d && h < H && w < W;
+            const long o = in[u] ? (long)c * L + (long)w * H + h : 0;
+            a2[u] = p2[o]; a3[u] = p3[o];
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int e = e0 + 256 * u;
+            if (in[u]) t[lds_idx(e >> 8, e & (kP - 1), (e >> 4) & (kP - 1))] += a2[u] + a3[u];
+        }
     }
     __syncthreads();
     // channels-last output: consecutive threads -> consecutive c
@@ -100,10 +128,23 @@ __global__ void __launch_bounds__(256) cross_split_kernel(const MergeArgs a) {
     const int c0 = ci * kC, w0 = wi * kP, h0 = hi * kP;
     const int tid = threadIdx.x;
     const float* __restrict__ db = a.dy + (long)b * L * d;
-    for (int e = tid; e < kC * kP * kP; e += 256) {
-        const int cl = e & (kC - 1), wl = (e >> 5) & (kP - 1), hl = e >> 9;
-        const int c = c0 + cl, h = h0 + hl, w = w0 + wl;
-        t[lds_idx(cl, hl, wl)] = (c < d && h < H && w < W) ? db[((long)h * W + w) * d + c] : 0.0f;
+    constexpr int kU = 8;                                  // loads of a batch all in flight together (see cross_merge_kernel)
+    for (int e0 = tid; e0 < kC * kP * kP; e0 += 256 * kU) {
+        float v[kU];
+        bool in[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int e = e0 + 256 * u;
+            const int cl = e & (kC - 1), wl = (e >> 5) & (kP - 1), hl = e >> 9;
+            const int c = c0 + cl, h = h0 + hl, w = w0 + wl;
+            in[u] = c < d && h < H && w < W;
+            v[u] = db[in[u] ? ((long)h * W + w) * d + c : 0];
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const int e = e0 + 256 * u;
+            t[lds_idx(e & (kC - 1), e >> 9, (e >> 5) & (kP - 1))] = in[u] ? v[u] : 0.0f;
+        }
     }
     __syncthreads();
     float* __restrict__ g_rm = a.g2 + ((long)(b * 2 + 0) * d) * L;
