@@ -56,16 +56,30 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(const LnArgs a) {
     // sample of the row for the per-sample factor: ONE division per wave, then carried along (a 64-bit division per row
     // cost more than the row itself at C <= 256: 69 -> 106 us on the 153600 x 192 backward)
     long sb = a.rsc ? wave / a.rows_per_scale : 0, srem = a.rsc ? wave - sb * a.rows_per_scale : 0;
-    for (long r = wave; r < a.M; r += nwaves) {
+    // The operands of the NEXT row are requested before the reductions of the current one (registers, two rows in flight
+    // per wave): a wave that loads, reduces twice and stores one row at a time keeps ~3 KB in flight, and the kernels
+    // then sit at 0.35-0.4 of the copy ceiling whatever the occupancy (profiles/r03_aux_roofline_v4.jsonl).
+    const bool gatedf = a.z != nullptr;
+    auto load_row = [&](long r, float4 (&xv)[NV], float4 (&zv)[NV]) {
         const float* __restrict__ xr = a.x + r * C;
-        float4 v[NV];
-        float s = 0.0f;
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             const int c = lane * 4 + 256 * j;
-            v[j] = c < C ? *reinterpret_cast<const float4*>(xr + c) : make_float4(0, 0, 0, 0);
-            s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+            xv[j] = c < C ? *reinterpret_cast<const float4*>(xr + c) : make_float4(0, 0, 0, 0);
+            zv[j] = (gatedf && c < C) ? *reinterpret_cast<const float4*>(a.z + r * a.z_stride + c) : make_float4(0, 0, 0, 0);
         }
+    };
+    constexpr bool kPrefetch = NV <= 2;        // wider rows: the second row in flight costs the occupancy it buys
+    float4 v[NV], zc[NV];
+    if (kPrefetch && wave < a.M) load_row(wave, v, zc);
+    for (long r = wave; r < a.M; r += nwaves) {
+        if (!kPrefetch) load_row(r, v, zc);
+        float4 vn[NV], zn[NV];
+        const bool more = kPrefetch && r + nwaves < a.M;
+        if (more) load_row(r + nwaves, vn, zn);
+        float s = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
         const float mu = wave_allsum(s) * inv;
         float q = 0.0f;
 #pragma unroll
@@ -78,7 +92,6 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(const LnArgs a) {
         }
         const float rs = rsqrtf(wave_allsum(q) * inv + a.eps);
         float* __restrict__ yr = a.y + r * C;
-        const float* __restrict__ zr = a.z ? a.z + r * a.z_stride : nullptr;
         float sc = 1.0f;
         if (a.rsc) {
             sc = a.rsc[sb];
@@ -94,8 +107,8 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(const LnArgs a) {
                 o.y = (v[j].y - mu) * rs * g[j].y + b[j].y;
                 o.z = (v[j].z - mu) * rs * g[j].z + b[j].z;
                 o.w = (v[j].w - mu) * rs * g[j].w + b[j].w;
-                if (zr) {
-                    const float4 zv = *reinterpret_cast<const float4*>(zr + c);
+                if (gatedf) {
+                    const float4 zv = zc[j];
                     o.x *= zv.x * sigmoid_f(zv.x); o.y *= zv.y * sigmoid_f(zv.y);
                     o.z *= zv.z * sigmoid_f(zv.z); o.w *= zv.w * sigmoid_f(zv.w);
                 }
@@ -104,6 +117,10 @@ __global__ void __launch_bounds__(256) ln_fwd_kernel(const LnArgs a) {
             }
         }
         if (lane == 0 && a.mean) { a.mean[r] = mu; a.rstd[r] = rs; }
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) { v[j] = vn[j]; zc[j] = zn[j]; }
+        }
     }
 }
 
@@ -124,10 +141,36 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const LnArgs a) {
     const bool gated = a.z != nullptr;
     const float inv = 1.0f / (float)C;
     long sb = a.rsc ? wave / a.rows_per_scale : 0, srem = a.rsc ? wave - sb * a.rows_per_scale : 0;
-    for (long r = wave; r < a.M; r += nwaves) {
+    // next row's operands requested before this row's reductions (see ln_fwd_kernel)
+    auto load_row = [&](long r, float4 (&xv)[NV], float4 (&gv)[NV], float4 (&zv)[NV], float& mu, float& rs) {
         const float* __restrict__ xr = a.x + r * C;
         const float* __restrict__ gr = a.dy + r * C;
-        const float mu = a.mean[r], rs = a.rstd[r];
+        mu = a.mean[r]; rs = a.rstd[r];
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int c = lane * 4 + 256 * j;
+            const bool in = c < C;
+            xv[j] = in ? *reinterpret_cast<const float4*>(xr + c) : make_float4(0, 0, 0, 0);
+            gv[j] = in ? *reinterpret_cast<const float4*>(gr + c) : make_float4(0, 0, 0, 0);
+            zv[j] = (gated && in) ? *reinterpret_cast<const float4*>(a.z + r * a.z_stride + c) : make_float4(0, 0, 0, 0);
+        }
+    };
+    float4 bv_[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int c = lane * 4 + 256 * j;
+        bv_[j] = (gated && a.beta && c < C) ? *reinterpret_cast<const float4*>(a.beta + c) : make_float4(0, 0, 0, 0);
+    }
+    constexpr bool kPrefetch = NV <= 2;
+    float4 xc[NV], gc[NV], zc[NV];
+    float mu = 0.0f, rs = 0.0f;
+    if (kPrefetch && wave < a.M) load_row(wave, xc, gc, zc, mu, rs);
+    for (long r = wave; r < a.M; r += nwaves) {
+        if (!kPrefetch) load_row(r, xc, gc, zc, mu, rs);
+        float4 xn[NV], gn[NV], zn[NV];
+        float mun = 0.0f, rsn = 0.0f;
+        const bool more = kPrefetch && r + nwaves < a.M;
+        if (more) load_row(r + nwaves, xn, gn, zn, mun, rsn);
         float sc = 1.0f;
         if (a.rsc) {
             sc = a.rsc[sb];
@@ -140,14 +183,14 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const LnArgs a) {
         for (int j = 0; j < NV; ++j) {
             const int c = lane * 4 + 256 * j;
             if (c < C) {
-                const float4 xv = *reinterpret_cast<const float4*>(xr + c);
-                float4 gv = *reinterpret_cast<const float4*>(gr + c);
+                const float4 xv = xc[j];
+                float4 gv = gc[j];
                 if (a.rsc) { gv.x *= sc; gv.y *= sc; gv.z *= sc; gv.w *= sc; }
                 xh[j] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
                 if (gated) {
                     // out = n * silu(z), n = xhat * gamma + beta:  dn = dout * silu(z),  dz = dout * n * silu'(z)
-                    const float4 zv = *reinterpret_cast<const float4*>(a.z + r * a.z_stride + c);
-                    const float4 bv = a.beta ? *reinterpret_cast<const float4*>(a.beta + c) : make_float4(0, 0, 0, 0);
+                    const float4 zv = zc[j];
+                    const float4 bv = bv_[j];
                     const float s0 = sigmoid_f(zv.x), s1_ = sigmoid_f(zv.y), s2_ = sigmoid_f(zv.z), s3 = sigmoid_f(zv.w);
                     float4 dzv;
                     dzv.x = gv.x * fmaf(xh[j].x, g[j].x, bv.x) * s0 * fmaf(zv.x, 1.0f - s0, 1.0f);
@@ -180,6 +223,11 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const LnArgs a) {
                 o.w = rs * (t[j].w - m1 - xh[j].w * m2);
                 *reinterpret_cast<float4*>(dr + c) = o;
             }
+        }
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) { xc[j] = xn[j]; gc[j] = gn[j]; zc[j] = zn[j]; }
+            mu = mun; rs = rsn;
         }
     }
     // the four waves of the workgroup meet in LDS: ONE partial (dgamma, dbeta) row per workgroup for ln_reduce_kernel

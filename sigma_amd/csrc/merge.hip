@@ -206,23 +206,36 @@ namespace {
 // acc[o][i] += src[2o][i] + src[2o+1][i]; 16 bytes per lane, grid-stride over (o, i / 4)
 __global__ void __launch_bounds__(256)
 pair_sum_add_kernel(const float* __restrict__ src, float* __restrict__ acc, long n_outer, long inner, int vec) {
-    if (vec) {
-        const long inner4 = inner >> 2;
-        const long total = n_outer * inner4;
-        for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
-            const long o = t / inner4, i4 = t - o * inner4;
-            const float4 a = reinterpret_cast<const float4*>(src + (2 * o) * inner)[i4];
-            const float4 b = reinterpret_cast<const float4*>(src + (2 * o + 1) * inner)[i4];
-            float4* dst = reinterpret_cast<float4*>(acc + o * inner) + i4;
-            float4 c = *dst;
-            c.x += a.x + b.x; c.y += a.y + b.y; c.z += a.z + b.z; c.w += a.w + b.w;
-            *dst = c;
-        }
-    } else {
-        const long total = n_outer * inner;
-        for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
-            const long o = t / inner, i = t - o * inner;
-            acc[t] += src[(2 * o) * inner + i] + src[(2 * o + 1) * inner + i];
+    // blockIdx.y walks the outer index (no division per element); four elements per thread and batch with all twelve
+    // loads issued before the first add (memory-level parallelism, see cross_merge_kernel)
+    constexpr int kU = 4;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long o = blockIdx.y; o < n_outer; o += gridDim.y) {
+        if (vec) {
+            const long inner4 = inner >> 2;
+            const float4* __restrict__ s0 = reinterpret_cast<const float4*>(src + (2 * o) * inner);
+            const float4* __restrict__ s1 = reinterpret_cast<const float4*>(src + (2 * o + 1) * inner);
+            float4* __restrict__ d = reinterpret_cast<float4*>(acc + o * inner);
+            for (long i0 = (long)blockIdx.x * blockDim.x + threadIdx.x; i0 < inner4; i0 += stride * kU) {
+                float4 a[kU], b[kU], c[kU];
+#pragma unroll
+                for (int u = 0; u < kU; ++u) {
+                    const long i = i0 + u * stride;
+                    const long ii = i < inner4 ? i : i0;
+                    a[u] = s0[ii]; b[u] = s1[ii]; c[u] = d[ii];
+                }
+#pragma unroll
+                for (int u = 0; u < kU; ++u) {
+                    const long i = i0 + u * stride;
+                    if (i < inner4) {
+                        c[u].x += a[u].x + b[u].x; c[u].y += a[u].y + b[u].y; c[u].z += a[u].z + b[u].z; c[u].w += a[u].w + b[u].w;
+                        d[i] = c[u];
+                    }
+                }
+            }
+        } else {
+            for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < inner; i += stride)
+                acc[o * inner + i] += src[(2 * o) * inner + i] + src[(2 * o + 1) * inner + i];
         }
     }
 }
@@ -235,10 +248,13 @@ int sigma_pair_sum_add(const float* src, float* acc, int64_t n_outer, int64_t in
     if (!src || !acc || n_outer < 0 || inner < 0) return SIGMA_OPS_ERR_ARG;
     if (n_outer == 0 || inner == 0) return SIGMA_OPS_OK;
     const int vec = (inner % 4 == 0) && (reinterpret_cast<uintptr_t>(src) % 16 == 0) && (reinterpret_cast<uintptr_t>(acc) % 16 == 0);
-    const long work = vec ? n_outer * (inner / 4) : n_outer * inner;
-    long blocks = (work + 255) / 256;
-    if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(sigma::pair_sum_add_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), src, acc,
+    const long per = vec ? inner / 4 : inner;                        // elements (of 16 or 4 bytes) per outer index
+    const long gy = n_outer < 65535 ? n_outer : 65535;
+    long gx = (per + 256 * 4 - 1) / (256 * 4);                       // four elements per thread
+    const long cap = (256 * 16 + gy - 1) / gy;                       // ~16 workgroups per CU in total
+    if (gx > cap) gx = cap;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(sigma::pair_sum_add_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, static_cast<hipStream_t>(stream), src, acc,
                        (long)n_outer, (long)inner, vec);
     return hipGetLastError() == hipSuccess ? SIGMA_OPS_OK : SIGMA_OPS_ERR_LAUNCH;
 }

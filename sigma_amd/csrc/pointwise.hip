@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <type_traits>
 
 #include "../../include/sigma_ops.h"
 #include "scan_device.h"
@@ -206,6 +207,80 @@ softmax_ce_bwd_kernel(const float* __restrict__ logits, const int64_t* __restric
     }
 }
 
+// Same kernels with the row (NC4 float4) held in registers: every load of a row is issued before the first use.  The
+// generic kernels above walk the row with one load in flight per thread (1.2 TB/s on 8 x 480 x 640 x 40).
+template <int NC4>
+__global__ void __launch_bounds__(256)
+softmax_ce_fwd_reg_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels, long rows, long ignore,
+                          float* __restrict__ lse, float* __restrict__ partial) {
+    __shared__ float sh[4];
+    constexpr int nc = NC4 * 4;
+    float loss = 0.0f, count = 0.0f;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += stride) {
+        const float4* __restrict__ xr = reinterpret_cast<const float4*>(logits + r * nc);
+        float4 v[NC4];
+#pragma unroll
+        for (int c = 0; c < NC4; ++c) v[c] = xr[c];
+        const long y = labels[r];
+        float m = kNegInf;
+#pragma unroll
+        for (int c = 0; c < NC4; ++c) m = fmaxf(m, fmaxf(fmaxf(v[c].x, v[c].y), fmaxf(v[c].z, v[c].w)));
+        float s = 0.0f, xy = 0.0f;
+#pragma unroll
+        for (int c = 0; c < NC4; ++c) {
+            s += (__expf(v[c].x - m) + __expf(v[c].y - m)) + (__expf(v[c].z - m) + __expf(v[c].w - m));
+            xy = (y == 4 * c) ? v[c].x : (y == 4 * c + 1) ? v[c].y : (y == 4 * c + 2) ? v[c].z : (y == 4 * c + 3) ? v[c].w : xy;
+        }
+        const float l = m + __logf(s);
+        lse[r] = l;
+        if (y != ignore && y >= 0 && y < nc) { loss += l - xy; count += 1.0f; }
+    }
+    const float tl = block_sum(loss, sh);
+    const float tc = block_sum(count, sh);
+    if (threadIdx.x == 0) { partial[2 * blockIdx.x] = tl; partial[2 * blockIdx.x + 1] = tc; }
+}
+
+template <int NC4>
+__global__ void __launch_bounds__(256)
+softmax_ce_bwd_reg_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels, const float* __restrict__ lse,
+                          const float* __restrict__ scale, long rows, long ignore, float* __restrict__ dlogits) {
+    constexpr int nc = NC4 * 4;
+    const float sc = scale[0];
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += stride) {
+        const float4* __restrict__ xr = reinterpret_cast<const float4*>(logits + r * nc);
+        float4* __restrict__ dr = reinterpret_cast<float4*>(dlogits + r * nc);
+        float4 v[NC4];
+#pragma unroll
+        for (int c = 0; c < NC4; ++c) v[c] = xr[c];
+        const long y = labels[r];
+        const float l = lse[r];
+        const float f = (y != ignore && y >= 0 && y < nc) ? sc : 0.0f;
+#pragma unroll
+        for (int c = 0; c < NC4; ++c) {
+            float4 o;
+            o.x = (__expf(v[c].x - l) - (y == 4 * c ? 1.0f : 0.0f)) * f;
+            o.y = (__expf(v[c].y - l) - (y == 4 * c + 1 ? 1.0f : 0.0f)) * f;
+            o.z = (__expf(v[c].z - l) - (y == 4 * c + 2 ? 1.0f : 0.0f)) * f;
+            o.w = (__expf(v[c].w - l) - (y == 4 * c + 3 ? 1.0f : 0.0f)) * f;
+            dr[c] = o;
+        }
+    }
+}
+
+// NC4 = classes / 4 held in registers up to 64 classes
+template <typename F>
+bool dispatch_nc4(int nc4, F&& f) {
+    switch (nc4) {
+#define SIGMA_NC4(N) case N: f(std::integral_constant<int, N>()); return true;
+        SIGMA_NC4(1) SIGMA_NC4(2) SIGMA_NC4(3) SIGMA_NC4(4) SIGMA_NC4(5) SIGMA_NC4(6) SIGMA_NC4(7) SIGMA_NC4(8)
+        SIGMA_NC4(9) SIGMA_NC4(10) SIGMA_NC4(11) SIGMA_NC4(12) SIGMA_NC4(13) SIGMA_NC4(14) SIGMA_NC4(15) SIGMA_NC4(16)
+#undef SIGMA_NC4
+        default: return false;
+    }
+}
+
 bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 unsigned stream_grid(long work_items) {
@@ -269,8 +344,14 @@ int sigma_softmax_ce_fwd(const float* logits, const int64_t* labels, int64_t row
     if (!partial) return SIGMA_OPS_ERR_ARG;
     if (rows > 0 && (!logits || !labels || !lse || !sigma::al16(logits))) return SIGMA_OPS_ERR_ARG;
     // every one of the SIGMA_CE_BLOCKS workgroups writes its (sum, count) pair, rows or not: the caller adds them up
-    hipLaunchKernelGGL(sigma::softmax_ce_fwd_kernel, dim3(SIGMA_CE_BLOCKS), dim3(256), 0, static_cast<hipStream_t>(stream), logits, labels,
-                       (long)rows, (int)classes, (long)ignore_index, lse, partial);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool reg = sigma::dispatch_nc4(classes / 4, [&](auto n) {
+        hipLaunchKernelGGL(sigma::softmax_ce_fwd_reg_kernel<decltype(n)::value>, dim3(SIGMA_CE_BLOCKS), dim3(256), 0, s, logits, labels,
+                           (long)rows, (long)ignore_index, lse, partial);
+    });
+    if (!reg)
+        hipLaunchKernelGGL(sigma::softmax_ce_fwd_kernel, dim3(SIGMA_CE_BLOCKS), dim3(256), 0, s, logits, labels, (long)rows, (int)classes,
+                           (long)ignore_index, lse, partial);
     return sigma::done();
 }
 
@@ -279,8 +360,14 @@ int sigma_softmax_ce_bwd(const float* logits, const int64_t* labels, const float
     if (rows < 0 || classes <= 0 || classes % 4 != 0) return SIGMA_OPS_ERR_ARG;
     if (rows == 0) return SIGMA_OPS_OK;
     if (!logits || !labels || !lse || !scale || !dlogits || !sigma::al16(logits) || !sigma::al16(dlogits)) return SIGMA_OPS_ERR_ARG;
-    hipLaunchKernelGGL(sigma::softmax_ce_bwd_kernel, dim3(sigma::stream_grid(rows)), dim3(256), 0, static_cast<hipStream_t>(stream), logits,
-                       labels, lse, scale, (long)rows, (int)classes, (long)ignore_index, dlogits);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool reg = sigma::dispatch_nc4(classes / 4, [&](auto n) {
+        hipLaunchKernelGGL(sigma::softmax_ce_bwd_reg_kernel<decltype(n)::value>, dim3(sigma::stream_grid(rows)), dim3(256), 0, s, logits,
+                           labels, lse, scale, (long)rows, (long)ignore_index, dlogits);
+    });
+    if (!reg)
+        hipLaunchKernelGGL(sigma::softmax_ce_bwd_kernel, dim3(sigma::stream_grid(rows)), dim3(256), 0, s, logits, labels, lse, scale,
+                           (long)rows, (int)classes, (long)ignore_index, dlogits);
     return sigma::done();
 }
 

@@ -54,7 +54,8 @@ def test_channel_gate_shares_the_max_gradient_between_ties():
     torch.testing.assert_close(grads[0], grads[1], rtol=2e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize("rows_shape,nc", [((2, 30, 40), 40), ((1, 7, 9), 12), ((8, 480, 640), 40), ((1, 1, 3), 4)])
+@pytest.mark.parametrize("rows_shape,nc", [((2, 30, 40), 40), ((1, 7, 9), 12), ((8, 480, 640), 40), ((1, 1, 3), 4), ((2, 9, 11), 64),
+                                           ((1, 5, 6), 72)])
 def test_softmax_cross_entropy_matches_torch(rows_shape, nc):
     from sigma_amd.pointwise import cross_entropy
     B, H, W = rows_shape
@@ -167,3 +168,15 @@ def test_vss_block_with_stochastic_depth_equals_masked_branch():
         outs.append([y.detach(), a.grad] + [p.grad.clone() for p in blk.parameters()])
     for i, (got, want) in enumerate(zip(outs[0], outs[1])):
         torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-5 * float(want.abs().max()) + 1e-7, msg=lambda m, i=i: f"tensor {i}: {m}")
+
+
+@pytest.mark.parametrize("n_outer,inner", [(32, 768 * 300), (3, 1001), (1, 4), (5, 4 * 1024 * 7 + 8)])
+def test_pair_sum_add_matches_torch(n_outer, inner):
+    """sigma_pair_sum_add (include/sigma_ops.h): acc[o] += src[2o] + src[2o + 1]"""
+    from sigma_amd.ss2d_fused import _pair_sum_add
+    g = torch.Generator().manual_seed(13)
+    src = torch.randn(n_outer, 2, inner, generator=g).cuda()
+    acc = torch.randn(n_outer, inner, generator=g).cuda()
+    want = acc + src[:, 0] + src[:, 1]
+    _pair_sum_add(src, acc, n_outer, inner)
+    torch.testing.assert_close(acc, want, rtol=0, atol=1e-6)
