@@ -33,7 +33,7 @@ def main():
             for r in csv.DictReader(open(f)):
                 if r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
                     kn = r["Kernel_Name"]
-                    k = "scan_fwd" if "scan_fwd_kernel" in kn else \
+                    k = "scan_fwd" if ("scan_fwd_kernel" in kn or "scan_fwd4_kernel" in kn) else \
                         "scan_bwd" if ("scan_bwd_kernel" in kn or "scan_bwd2_kernel" in kn or "scan_bwd3_kernel" in kn or "scan_bwd4_kernel" in kn) else \
                         "reduce_partials" if "reduce_partials" in kn else None
                     if k:
