@@ -1,0 +1,146 @@
+"""Host-side logic added in round 3, checked on CPU tensors (the HIP kernels behind it are covered by -m gpu tests):
+layout helpers, stochastic depth folded into the branch, the applicability rules of the fused loss, the evaluator's
+window grid, the GEMM wrappers' refusal of CPU tensors."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+
+def test_layout_helpers_on_cpu_are_the_torch_permutes():
+    from sigma_amd.layout import channels_first, channels_last, transpose_rows
+    x = torch.randn(2, 5, 7, 12)
+    assert torch.equal(channels_first(x), x.permute(0, 3, 1, 2)) and channels_first(x).is_contiguous()
+    y = torch.randn(2, 12, 5, 7)
+    assert torch.equal(channels_last(y), y.permute(0, 2, 3, 1)) and channels_last(y).is_contiguous()
+    s = torch.randn(3, 6, 20)
+    h = s.split(10, dim=-1)[1]
+    assert torch.equal(transpose_rows(h), h.transpose(1, 2)) and transpose_rows(h).is_contiguous()
+    with pytest.raises(RuntimeError):
+        transpose_rows(torch.randn(4, 4))
+
+
+def test_drop_path_draw_is_the_mask_add_to_applies():
+    import importlib
+    vm = importlib.import_module("sigma_amd.models.encoders.vmamba")
+    dp = vm.DropPath(0.4).train()
+    x, r = torch.randn(16, 3, 4, 5), torch.randn(16, 3, 4, 5)
+    torch.manual_seed(5)
+    mask = dp.draw(x)
+    torch.manual_seed(5)
+    out = dp.add_to(r, x)
+    assert tuple(mask.shape) == (16, 1, 1, 1)
+    assert all(v == 0.0 or abs(v - 1 / 0.6) < 1e-5 for v in mask.flatten().tolist())
+    torch.testing.assert_close(out, r + x * mask)
+    assert dp.eval().draw(x) is None and vm.DropPath(0.0).train().draw(x) is None
+    torch.testing.assert_close(dp.add_to(r, x), r + x)                      # eval: plain residual
+
+
+def test_vss_and_cvss_blocks_fold_the_mask_into_the_branch(monkeypatch):
+    """x + mask * op(norm(x)) (vmamba.py:1716-1722) and x * scale1 + mask * op(norm1(x)) (:1800-1802) with the mask handed
+    to the branch: checked with the branch replaced by a linear map (the scan itself needs the GPU)."""
+    import importlib
+    vm = importlib.import_module("sigma_amd.models.encoders.vmamba")
+
+    class Branch(nn.Module):
+        def __init__(self, C):
+            super().__init__()
+            self.lin = nn.Linear(C, C, bias=False)
+
+        def forward(self, x, branch_scale=None):
+            y = self.lin(x)
+            return y if branch_scale is None else y * branch_scale
+
+    C = 8
+    blk = vm.VSSBlock(hidden_dim=C, drop_path=0.5, d_state=4).train()
+    blk.op = Branch(C)
+    x = torch.randn(6, 3, 4, C)
+    torch.manual_seed(2)
+    got = blk(x)
+    torch.manual_seed(2)
+    mask = blk.drop_path.draw(x)
+    torch.testing.assert_close(got, x + blk.op(blk.norm(x)) * mask)
+
+    dec = vm.CVSSDecoderBlock(hidden_dim=96, drop_path=0.5, d_state=4).train()
+    dec.op = Branch(96)
+    with torch.no_grad():
+        dec.scale1.copy_(torch.randn(96))
+        dec.scale2.copy_(torch.randn(96))
+    z = torch.randn(4, 6, 5, 96)
+    torch.manual_seed(3)
+    got = dec(z)
+    torch.manual_seed(3)
+    mask = dec.drop_path.draw(z)
+    mid = z * dec.scale1 + dec.op(dec.norm1(z)) * mask
+    want = mid * dec.scale2 + dec.conv_blk(dec.norm2(mid).permute(0, 3, 1, 2).contiguous()).permute(0, 2, 3, 1)
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-6)
+
+
+def test_fused_cross_entropy_only_takes_what_it_computes():
+    from sigma_amd.pointwise import cross_entropy
+    logits = torch.randn(1, 6, 6, 12).permute(0, 3, 1, 2)
+    label = torch.zeros(1, 6, 6, dtype=torch.long)
+    assert cross_entropy(nn.CrossEntropyLoss(), logits, label) is None                      # CPU tensors: not this path
+    assert cross_entropy(nn.CrossEntropyLoss(reduction="sum"), logits, label) is None
+    assert cross_entropy(nn.CrossEntropyLoss(weight=torch.ones(12)), logits, label) is None
+    assert cross_entropy(nn.CrossEntropyLoss(label_smoothing=0.1), logits, label) is None
+    assert cross_entropy(nn.MSELoss(), logits, label) is None
+
+
+def test_builder_forward_uses_the_criterion_when_the_fused_loss_declines():
+    """EncoderDecoder.forward (models/builder.py:146-157): loss = criterion(logits, label) -- on CPU tensors through the
+    criterion itself, whatever it is."""
+    from sigma_amd.models.builder import EncoderDecoder
+
+    class Stub(EncoderDecoder):
+        def __init__(self):
+            nn.Module.__init__(self)
+            self.criterion = nn.CrossEntropyLoss(reduction="mean", ignore_index=255)
+
+        def encode_decode(self, rgb, modal_x):
+            return rgb[:, :3] * 2.0
+
+    m = Stub()
+    rgb = torch.randn(2, 3, 4, 5)
+    label = torch.randint(0, 3, (2, 4, 5))
+    torch.testing.assert_close(m(rgb, rgb, label), nn.functional.cross_entropy(rgb * 2.0, label))
+    assert m(rgb, rgb).is_contiguous() and torch.equal(m(rgb, rgb), rgb * 2.0)
+
+
+def test_evaluator_window_grid_reproduces_the_reference_arithmetic():
+    """engine/evaluator.py:464-478, including its use of stride[0] / crop_size[0] for the column direction"""
+    from sigma_amd.engine.evaluator_ops import window_grid
+    crop, rate, rows, cols = (256, 256), 2 / 3, 600, 800
+    stride = (int(np.ceil(crop[0] * rate)), int(np.ceil(crop[1] * rate)))
+    r_grid = int(np.ceil((rows - crop[0]) / stride[0])) + 1
+    c_grid = int(np.ceil((cols - crop[1]) / stride[1])) + 1
+    ref = []
+    for gy in range(r_grid):                       # the reference's loop, literally
+        for gx in range(c_grid):
+            s_x, s_y = gx * stride[0], gy * stride[1]
+            e_x, e_y = min(s_x + crop[0], cols), min(s_y + crop[1], rows)
+            s_x, s_y = e_x - crop[0], e_y - crop[1]
+            ref.append((s_y, e_y, s_x, e_x))
+    wins = window_grid(rows, cols, crop, rate)
+    assert wins == ref and len(wins) == r_grid * c_grid
+    covered = np.zeros((rows, cols), dtype=bool)
+    for s_y, e_y, s_x, e_x in wins:
+        covered[s_y:e_y, s_x:e_x] = True
+    assert covered.all()
+    # a non-square crop on an image that is shorter than crop[1]: the reference's mixed indices give a negative start (its
+    # numpy slicing would silently wrap around); here that is an error instead of wrong scores
+    with pytest.raises(ValueError):
+        window_grid(600, 800, (480, 640), 2 / 3)
+
+
+def test_gemm_and_gate_wrappers_refuse_cpu_tensors():
+    from sigma_amd import gemm
+    from sigma_amd.pointwise import channel_gate
+    a, b = torch.randn(8, 16), torch.randn(4, 16)
+    for fn in (gemm.gemm_nt, gemm.gemm_tn):
+        with pytest.raises(RuntimeError):
+            fn(a, b if fn is gemm.gemm_nt else torch.randn(8, 4))
+    with pytest.raises(RuntimeError):
+        gemm.linear(torch.randn(2, 3, 16), b)
+    with pytest.raises(RuntimeError):
+        channel_gate(torch.randn(1, 8, 3, 3), torch.randn(2, 8, 1, 1), torch.randn(8, 2, 1, 1))
