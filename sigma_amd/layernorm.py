@@ -99,6 +99,7 @@ class LayerNormFn(torch.autograd.Function):
         if ctx.gated:
             if ctx.gate_half:
                 full = torch.empty(*ctx.gate_shape[:-1], 2 * C, device=xc.device, dtype=torch.float32)
+                full._sigma_xz_grad = True        # SplitXZFn.backward completes THIS buffer in place, and no other
                 dz = full[..., C:]
                 p.dgate_row_stride = 2 * C
             else:

@@ -189,7 +189,8 @@ class SplitXZFn(torch.autograd.Function):
         B, H, W, d = ctx.dims
         L = H * W
         base = dz._base if dz is not None else None
-        if (base is not None and tuple(base.shape) == (B, H, W, 2 * d) and base.is_contiguous() and base.dtype == dx.dtype
+        if (base is not None and getattr(base, "_sigma_xz_grad", False) and tuple(base.shape) == (B, H, W, 2 * d)
+                and base.is_contiguous() and base.dtype == dx.dtype
                 and tuple(dz.shape) == (B, H, W, d) and dz.data_ptr() == base.data_ptr() + 4 * d and dz.stride(-1) == 1
                 and dz.stride(-2) == 2 * d):
             dxz = base                    # the gated LayerNorm's backward wrote dz into the z half already (layernorm.py)
