@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SIGMA_SCAN_ABI_VERSION 6
+#define SIGMA_SCAN_ABI_VERSION 7
 
 /* dtype of u, delta, B, C, out, dout, du, ddelta  (input_t of the reference,
  * selective_scan.cpp:174: float / half / bfloat16).  A, D, delta_bias, x, dA,
@@ -70,12 +70,22 @@ enum sigma_status {
  * the quad-row kernels (scan_fwd4.hip / scan_bwd4.hip: a wave = 4 channel rows x 16 lanes x 10 positions; with few rows
  * the backward additionally splits the sequence into segments): f32 IO, dstate in {4, 8, 16}, rows per group divisible
  * by 4, seqlen % 4 == 0, 16-byte aligned operands -- the backward fails with SIGMA_ERR_BAD_SHAPE otherwise (the forward
- * falls back to the 64-lane kernel, which writes the same checkpoints).  Unused slots are not written. */
+ * falls back to the 64-lane kernel, which writes the same checkpoints).  Unused slots are not written.
+ * Pitch 16 selects the row-lane kernels (scan_fwdr.hip / scan_bwdr.hip: a lane = a channel row, a wave = 64 rows x a
+ * quarter / an eighth of the states, B and C as scalar operands): f32 IO, dstate in {4, 8, 16}, rows per group divisible
+ * by 64, seqlen % 4 == 0, 16-byte aligned operands; BOTH entry points fail with SIGMA_ERR_BAD_SHAPE otherwise.  x then
+ * holds 2 * ceil(seqlen / 16) * dstate floats per row (one checkpoint per 8 positions; the backward walks its 16-position
+ * tiles as two halves) in a layout private to the two kernels (x_row_stride is ignored):
+ *     x[((((b * dim/64 + r/64) * ceil(L/16) + tile) * 2 + h) * N + n) * 64 + r % 64] = state n of row r after the first
+ *     half (h = 0, scan order) / after the whole (h = 1) of memory tile `tile`.
+ * With few rows both kernels cut the sequence into segments run by different workgroups (a pre-pass writes per-segment
+ * summaries into the workspace): see sigma_scan_fwd_workspace_bytes / sigma_scan_bwd_workspace_bytes. */
 #define SIGMA_SCAN_CHUNK 2048
 #define SIGMA_SCAN_CKPT_PITCH 1280
 #define SIGMA_SCAN_CKPT_PITCH_FINE 640
 #define SIGMA_SCAN_CKPT_PITCH_160 160
 #define SIGMA_SCAN_CKPT_PITCH_320 320
+#define SIGMA_SCAN_CKPT_PITCH_16 16
 /* dstate limit of the reference (selective_scan.cpp:10,201). */
 #define SIGMA_SCAN_MAX_DSTATE 256
 
@@ -99,7 +109,7 @@ typedef struct sigma_scan_fwd_params {
      *      flip share one physical copy of x. */
     uint32_t rev_group_mask;
     int32_t u_group_shift;
-    int32_t ckpt_pitch;        /* 0 = SIGMA_SCAN_CKPT_PITCH (1280); 640 / 320 / 160 = fine checkpoints (see above) */
+    int32_t ckpt_pitch;        /* 0 = SIGMA_SCAN_CKPT_PITCH (1280); 640 / 320 / 160 / 16 = fine checkpoints (see above) */
     int32_t param_group_swap;  /* 1 (needs n_groups == 4): A, D, delta_bias and dA, dD, ddelta_bias keep the REFERENCE's direction
                                   order k = [row, col, row reversed, col reversed] (vmamba.py:84-89) while the sequence
                                   operands use the kernel's group order g = 2*order + reversed: group g reads / writes the
@@ -125,6 +135,10 @@ typedef struct sigma_scan_fwd_params {
     int64_t B_batch_stride, B_group_stride, B_dstate_stride;
     int64_t C_batch_stride, C_group_stride, C_dstate_stride;
     int64_t out_batch_stride, out_d_stride;
+    /* device scratch of >= sigma_scan_fwd_workspace_bytes() bytes, 16-byte aligned (ckpt_pitch 16 with few rows: the
+     * forward summaries of the sequence segments); may be NULL when that function returns 0.  Unused by the backward. */
+    void *workspace;
+    int64_t workspace_bytes;
 } sigma_scan_fwd_params;
 
 typedef struct sigma_scan_bwd_params {
@@ -163,6 +177,10 @@ int sigma_selective_scan_fwd(const sigma_scan_fwd_params *params, void *stream);
 /* Backward: du, ddelta, dB, dC written; dA, dD, ddelta_bias accumulated (+=). */
 int sigma_selective_scan_bwd(const sigma_scan_bwd_params *params, void *stream);
 
+/* Scratch bytes sigma_selective_scan_fwd needs for this problem under the current options (non-zero only for
+ * ckpt_pitch 16 when the sequence is cut into segments); negative = invalid params. */
+int64_t sigma_scan_fwd_workspace_bytes(const sigma_scan_fwd_params *params);
+
 /* Scratch bytes sigma_selective_scan_bwd needs for this problem under the current options: the per-workgroup dB/dC
  * partials (0 when one workgroup covers a whole (batch, group)) plus the segment summaries of a split sequence;
  * negative = invalid params. */
@@ -193,6 +211,8 @@ int sigma_scan_abi_version(void);
  *   "bwd_sb"                   quad-row backward (ckpt_pitch 160): states per barrier {1, 2, 4, 8}; 0 = 2
  *   "bwd_seg"                  quad-row backward: sequence segments {2,3,4,6,8,12}; 1 = never split; 0 = cost model
  *   "bwd_wgs"                  quad-row backward: 2 = two workgroups of <= 8 waves per CU (A/B knob)
+ *   "rl_waves"                 row-lane kernels (ckpt_pitch 16): state waves per 64-row block {4, 8, 16}; 0 = cost model
+ *   "rl_segs"                  row-lane kernels: sequence segments (1 = never split, 2..64); 0 = cost model
  * Returns SIGMA_ERR_BAD_OPTION for unknown names / unsupported values. */
 int sigma_scan_set_option(const char *name, int value);
 int sigma_scan_get_option(const char *name);

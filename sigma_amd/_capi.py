@@ -14,12 +14,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SIGMA_HIP_LIB lets a benchmark A/B an experimental build of the same ABI; default is the in-tree library
 LIB_PATH = os.environ.get("SIGMA_HIP_LIB") or os.path.join(_HERE, "lib", "libsigma_hip.so")
 
-SIGMA_SCAN_ABI_VERSION = 6
+SIGMA_SCAN_ABI_VERSION = 7
 SIGMA_SCAN_CHUNK = 2048
 SIGMA_SCAN_CKPT_PITCH = 1280
 SIGMA_SCAN_CKPT_PITCH_FINE = 640
 SIGMA_SCAN_CKPT_PITCH_320 = 320
 SIGMA_SCAN_CKPT_PITCH_160 = 160
+SIGMA_SCAN_CKPT_PITCH_16 = 16
 SIGMA_SCAN_MAX_DSTATE = 256
 
 DTYPE_F32, DTYPE_F16, DTYPE_BF16 = 0, 1, 2
@@ -46,6 +47,7 @@ class FwdParams(ctypes.Structure):
         ("B_batch_stride", ctypes.c_int64), ("B_group_stride", ctypes.c_int64), ("B_dstate_stride", ctypes.c_int64),
         ("C_batch_stride", ctypes.c_int64), ("C_group_stride", ctypes.c_int64), ("C_dstate_stride", ctypes.c_int64),
         ("out_batch_stride", ctypes.c_int64), ("out_d_stride", ctypes.c_int64),
+        ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_int64),
     ]
 
 
@@ -147,6 +149,7 @@ EXPORTED_SYMBOLS = (
     "sigma_selective_scan_fwd",
     "sigma_selective_scan_bwd",
     "sigma_scan_bwd_workspace_bytes",
+    "sigma_scan_fwd_workspace_bytes",
     "sigma_scan_last_error",
     "sigma_scan_abi_version",
     "sigma_scan_set_option",
@@ -180,6 +183,8 @@ def load() -> ctypes.CDLL:
     lib.sigma_selective_scan_bwd.restype = ctypes.c_int
     lib.sigma_scan_bwd_workspace_bytes.argtypes = [P(BwdParams)]
     lib.sigma_scan_bwd_workspace_bytes.restype = ctypes.c_int64
+    lib.sigma_scan_fwd_workspace_bytes.argtypes = [P(FwdParams)]
+    lib.sigma_scan_fwd_workspace_bytes.restype = ctypes.c_int64
     lib.sigma_scan_last_error.argtypes = []
     lib.sigma_scan_last_error.restype = ctypes.c_char_p
     lib.sigma_scan_abi_version.argtypes = []

@@ -21,6 +21,7 @@ thread_local std::string g_err;
 std::atomic<int> g_opt_fwd_items{0}, g_opt_fwd_waves{0}, g_opt_fwd_tiles{0}, g_opt_fwd_nb{0};
 std::atomic<int> g_opt_bwd_items{0}, g_opt_bwd_waves{0}, g_opt_bwd_nb{0}, g_opt_no_glds{0}, g_opt_bwd_slab2{0}, g_opt_fwd_prefetch{0};
 std::atomic<int> g_opt_bwd_gen{0}, g_opt_bwd_rb{0}, g_opt_bwd_touch{0}, g_opt_bwd_sb{0}, g_opt_bwd_wgs{0}, g_opt_fwd_gen{0}, g_opt_bwd_seg{0};
+std::atomic<int> g_opt_rl_waves{0}, g_opt_rl_segs{0};
 
 int fail(int code, const char* fmt, ...) {
     char buf[512];
@@ -54,10 +55,10 @@ int check_fwd(const sigma_scan_fwd_params* p, bool need_out, bool need_ptrs = tr
     if (p->rev_group_mask != 0 && (p->n_groups > 32 || (p->n_groups < 32 && (p->rev_group_mask >> p->n_groups) != 0)))
         return fail(SIGMA_ERR_BAD_SHAPE, "rev_group_mask 0x%x names groups >= n_groups (%d)", p->rev_group_mask, p->n_groups);
     if (p->ckpt_pitch != 0 && p->ckpt_pitch != SIGMA_SCAN_CKPT_PITCH && p->ckpt_pitch != SIGMA_SCAN_CKPT_PITCH_FINE &&
-        p->ckpt_pitch != SIGMA_SCAN_CKPT_PITCH_320 && p->ckpt_pitch != SIGMA_SCAN_CKPT_PITCH_160)
-        return fail(SIGMA_ERR_BAD_SHAPE, "ckpt_pitch must be 0, %d, %d, %d or %d (got %d)", SIGMA_SCAN_CKPT_PITCH,
-                    SIGMA_SCAN_CKPT_PITCH_FINE, SIGMA_SCAN_CKPT_PITCH_320, SIGMA_SCAN_CKPT_PITCH_160, p->ckpt_pitch);
-    {
+        p->ckpt_pitch != SIGMA_SCAN_CKPT_PITCH_320 && p->ckpt_pitch != SIGMA_SCAN_CKPT_PITCH_160 && p->ckpt_pitch != SIGMA_SCAN_CKPT_PITCH_16)
+        return fail(SIGMA_ERR_BAD_SHAPE, "ckpt_pitch must be 0, %d, %d, %d, %d or %d (got %d)", SIGMA_SCAN_CKPT_PITCH,
+                    SIGMA_SCAN_CKPT_PITCH_FINE, SIGMA_SCAN_CKPT_PITCH_320, SIGMA_SCAN_CKPT_PITCH_160, SIGMA_SCAN_CKPT_PITCH_16, p->ckpt_pitch);
+    if (p->ckpt_pitch != SIGMA_SCAN_CKPT_PITCH_16) {
         const int pitch = p->ckpt_pitch ? p->ckpt_pitch : SIGMA_SCAN_CKPT_PITCH;
         const int64_t need = (int64_t)((p->seqlen + pitch - 1) / pitch) * p->dstate;
         const int64_t have = p->x_row_stride ? p->x_row_stride : (int64_t)p->n_chunks * 2 * p->dstate;
@@ -477,6 +478,70 @@ Plan4 plan_bwd4(const sigma_scan_fwd_params* p, bool vec) {
     return pl;
 }
 
+// Row-lane kernels (scan_fwdr.hip / scan_bwdr.hip, ckpt_pitch 16): a workgroup is one 64-row block of a (batch, group)
+// x NW state waves (dstate / NW states each); with few rows the sequence is cut into S segments of seg_tiles 16-position
+// tiles (a summary pre-pass provides the state / reverse carry entering a segment).
+struct PlanR { bool ok; int NW, P, S, seg_tiles, grid; };
+
+bool rowlane_legal(const sigma_scan_fwd_params* p, bool vec) {
+    const int N = p->dstate;
+    if (p->ckpt_pitch != SIGMA_SCAN_CKPT_PITCH_16) return false;
+    if (N != 4 && N != 8 && N != 16) return false;
+    if (p->io_dtype != SIGMA_DTYPE_F32 || !vec || (p->seqlen % 4) != 0) return false;
+    if ((p->dim / p->n_groups) % 64 != 0) return false;
+    const int64_t span = (int64_t)N * (p->B_dstate_stride > p->C_dstate_stride ? p->B_dstate_stride : p->C_dstate_stride) + p->seqlen;
+    return p->B_dstate_stride >= 0 && p->C_dstate_stride >= 0 && span * 4 < (int64_t(1) << 31);
+}
+
+PlanR plan_rowlane(const sigma_scan_fwd_params* p, bool vec, bool backward) {
+    PlanR pl;
+    std::memset(&pl, 0, sizeof(pl));
+    if (!rowlane_legal(p, vec)) return pl;
+    const int N = p->dstate;
+    const int P = (p->dim / p->n_groups) / 64;
+    const long nwg0 = (long)p->batch * p->n_groups * P;
+    const int ntiles = (p->seqlen + 15) / 16;
+    // candidates (state waves, workgroups a CU holds: registers / LDS of the builds, see the kernel files)
+    struct Cand { int nw, wgpc; };
+    Cand cf16[] = {{4, 3}, {8, 2}, {16, 1}}, cf8[] = {{4, 4}, {8, 2}}, cf4[] = {{4, 4}};
+    Cand cb16[] = {{4, 2}}, cb8[] = {{4, 2}}, cb4[] = {{4, 2}};
+    const Cand* cand = backward ? (N == 16 ? cb16 : N == 8 ? cb8 : cb4) : (N == 16 ? cf16 : N == 8 ? cf8 : cf4);
+    const int ncand = backward ? 1 : (N == 16 ? 3 : N == 8 ? 2 : 1);
+    const int fw = g_opt_rl_waves.load(), fs = g_opt_rl_segs.load();
+    // per-wave cost of one tile in issue clocks: NS states x 16 positions x clocks per element-state + fixed part
+    const double ces = backward ? 55.0 : 17.7, fixed = backward ? 600.0 : 360.0, pre = backward ? 1.45 : 2.0;
+    double best = 1e300;
+    for (int ci = 0; ci < ncand; ++ci) {
+        const int nw = cand[ci].nw;
+        if (fw != 0 && fw != nw) {
+            bool legal = false;
+            for (int cj = 0; cj < ncand; ++cj) legal = legal || cand[cj].nw == fw;
+            if (legal) continue;                                   // a forced value this build has
+        }
+        const long slots = (long)kCUs * cand[ci].wgpc;
+        for (int S = 1; S <= 64; ++S) {
+            if (fs != 0 && S != fs && !(fs > 1 && (ntiles + fs - 1) / fs < 2)) continue;
+            const int st = (ntiles + S - 1) / S;
+            if (S > 1 && (st < 2 || (long)st * (S - 1) >= ntiles)) continue;      // >= 2 tiles each, none empty
+            const long nwg = nwg0 * S;
+            const double rounds = (double)((nwg + slots - 1) / slots);
+            double wres = (double)(nwg < slots ? nwg : slots) * nw / (4.0 * kCUs);   // resident waves per SIMD
+            if (wres < 1.9) wres = 1.9;                            // a lone wave issues every ~4.5 clocks
+            const double t = rounds * st * wres * ((N / nw) * 16 * ces + fixed) * (S > 1 ? pre : 1.0);
+            if (t < best * 0.999) { best = t; pl.NW = nw; pl.S = S; pl.seg_tiles = st; }
+        }
+    }
+    if (pl.NW == 0) return pl;
+    pl.ok = true;
+    pl.P = P;
+    pl.grid = (int)(nwg0 * pl.S);
+    return pl;
+}
+
+int64_t rowlane_summary_floats(const sigma_scan_fwd_params* p, int S) {
+    return S > 1 ? (int64_t)(S - 1) * p->batch * p->dim * (int64_t)p->dstate * 2 : 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -505,6 +570,8 @@ OptDesc g_opts[] = {
     {"bwd_sb", &g_opt_bwd_sb, {0, 1, 2, 4, 8, -1}},          // quad-row backward: states per barrier (0 = 2)
     {"bwd_touch", &g_opt_bwd_touch, {0, 1, 2, -1}},   // L2 warm-up touches of the next row step: 1 = on, 2 = off, 0 = on in scan_bwd4 only
     {"bwd_rb", &g_opt_bwd_rb, {-3}},                       // scan_bwd2: row blocks per workgroup, 0..256
+    {"rl_waves", &g_opt_rl_waves, {0, 4, 8, 16, -1}},       // row-lane kernels: state waves per 64-row block
+    {"rl_segs", &g_opt_rl_segs, {-4}},                      // row-lane kernels: sequence segments, 0..64
 };
 }  // namespace
 
@@ -515,6 +582,7 @@ int sigma_scan_set_option(const char* name, int value) {
         bool ok = false;
         if (o.allowed[0] == -2) ok = value >= 0 && value <= 16;
         else if (o.allowed[0] == -3) ok = value >= 0 && value <= 256;
+        else if (o.allowed[0] == -4) ok = value >= 0 && value <= 64;
         else for (int i = 0; i < 8 && o.allowed[i] != -1; ++i) ok = ok || o.allowed[i] == value;
         if (!ok) return fail(SIGMA_ERR_BAD_OPTION, "value %d not allowed for option '%s'", value, name);
         *o.var = value;
@@ -533,6 +601,13 @@ int sigma_scan_fwd_plan(const sigma_scan_fwd_params* p, int32_t plan[6]) {
     int rc = check_fwd(p, false, false);
     if (rc) return rc;
     if (!plan) return fail(SIGMA_ERR_NULL_ARG, "plan is NULL");
+    if (p->ckpt_pitch == SIGMA_SCAN_CKPT_PITCH_16) {
+        const PlanR pr = plan_rowlane(p, true, false);
+        if (!pr.ok) return fail(SIGMA_ERR_BAD_SHAPE, "ckpt_pitch 16 (row-lane kernels) is not available for this problem");
+        // items 16, rows slot = state waves, tiles slot = segments, states_per_block slot = -200
+        plan[0] = 16; plan[1] = pr.NW; plan[2] = pr.grid; plan[3] = (int32_t)sigma::fwdr_lds_bytes(pr.NW); plan[4] = pr.S; plan[5] = -200;
+        return SIGMA_OK;
+    }
     const PlanF4 p4 = plan_fwd4(p, true);
     if (p4.ok) {      // quad-row forward: items 10, rows slot = waves (4 rows each), states_per_block slot = -100
         plan[0] = 10; plan[1] = p4.W; plan[2] = p4.grid; plan[3] = (int32_t)p4.lds; plan[4] = 1; plan[5] = -100;
@@ -548,6 +623,12 @@ int sigma_scan_bwd_plan(const sigma_scan_bwd_params* p, int32_t plan[6]) {
     int rc = check_fwd(&p->fwd, false, false);
     if (rc) return rc;
     if (!plan) return fail(SIGMA_ERR_NULL_ARG, "plan is NULL");
+    if (p->fwd.ckpt_pitch == SIGMA_SCAN_CKPT_PITCH_16) {
+        const PlanR pr = plan_rowlane(&p->fwd, true, true);
+        if (!pr.ok) return fail(SIGMA_ERR_BAD_SHAPE, "ckpt_pitch 16 (row-lane kernels) is not available for this problem");
+        plan[0] = 16; plan[1] = pr.NW; plan[2] = pr.grid; plan[3] = (int32_t)sigma::bwdr_lds_bytes(4); plan[4] = pr.S; plan[5] = -200;
+        return SIGMA_OK;
+    }
     if (p->fwd.ckpt_pitch == SIGMA_SCAN_CKPT_PITCH_160) {
         const Plan4 p4 = plan_bwd4(&p->fwd, true);
         if (!p4.ok) return fail(SIGMA_ERR_BAD_SHAPE, "ckpt_pitch 160 (quad-row backward) is not available for this problem");
@@ -576,6 +657,23 @@ int sigma_selective_scan_fwd(const sigma_scan_fwd_params* p, void* stream) {
     if (rc) return rc;
     if (p->batch == 0 || p->seqlen == 0) return SIGMA_OK;
     const bool vec = vec_ok_fwd(p, true) && (p->rev_group_mask == 0 || p->seqlen % 4 == 0);
+    if (p->ckpt_pitch == SIGMA_SCAN_CKPT_PITCH_16) {
+        const PlanR pr = plan_rowlane(p, vec, false);
+        if (!pr.ok)
+            return fail(SIGMA_ERR_BAD_SHAPE, "ckpt_pitch 16 needs f32 IO, 16-byte aligned operands, dstate in {4,8,16}, seqlen %% 4 == 0 and rows per group divisible by 64");
+        const int64_t need = rowlane_summary_floats(p, pr.S) * (int64_t)sizeof(float);
+        if (need > 0) {
+            if (!p->workspace || p->workspace_bytes < need)
+                return fail(SIGMA_ERR_NULL_ARG, "forward workspace of %lld bytes required (got %lld)", (long long)need, (long long)p->workspace_bytes);
+            if (!aligned_to(p->workspace, 16)) return fail(SIGMA_ERR_BAD_STRIDE, "workspace must be 16-byte aligned");
+        }
+        sigma::FwdArgs a = make_fwd_args(p, pr.NW, 1, p->dstate, vec);
+        a.rowblocks = pr.P; a.segs = pr.S; a.seg_tiles = pr.seg_tiles;
+        a.fsumm = need > 0 ? static_cast<float*>(p->workspace) : nullptr;
+        hipError_t e = sigma::launch_scan_fwdr(a, static_cast<hipStream_t>(stream));
+        if (e != hipSuccess) return fail(SIGMA_ERR_LAUNCH, "scan_fwdr launch failed: %s", hipGetErrorString(e));
+        return SIGMA_OK;
+    }
     const PlanF4 p4 = plan_fwd4(p, vec);
     if (p4.ok) {
         sigma::FwdArgs a = make_fwd_args(p, p4.W, 1, p->dstate, vec);
@@ -604,11 +702,26 @@ bool vec_ok_bwd(const sigma_scan_bwd_params* q) {
 }
 }  // namespace
 
+int64_t sigma_scan_fwd_workspace_bytes(const sigma_scan_fwd_params* p) {
+    if (!p) { fail(SIGMA_ERR_NULL_ARG, "params is NULL"); return -1; }
+    if (check_fwd(p, false, false)) return -1;
+    if (p->batch == 0 || p->seqlen == 0 || p->ckpt_pitch != SIGMA_SCAN_CKPT_PITCH_16) return 0;
+    const PlanR pr = plan_rowlane(p, true, false);
+    if (!pr.ok) { fail(SIGMA_ERR_BAD_SHAPE, "ckpt_pitch 16 (row-lane kernels) is not available for this problem"); return -1; }
+    return rowlane_summary_floats(p, pr.S) * (int64_t)sizeof(float);
+}
+
 int64_t sigma_scan_bwd_workspace_bytes(const sigma_scan_bwd_params* q) {
     if (!q) { fail(SIGMA_ERR_NULL_ARG, "params is NULL"); return -1; }
     const sigma_scan_fwd_params* p = &q->fwd;
     if (check_fwd(p, false, false)) return -1;
     if (p->batch == 0 || p->seqlen == 0) return 0;
+    if (p->ckpt_pitch == SIGMA_SCAN_CKPT_PITCH_16) {
+        const PlanR pr = plan_rowlane(p, true, true);
+        if (!pr.ok) { fail(SIGMA_ERR_BAD_SHAPE, "ckpt_pitch 16 (row-lane kernels) is not available for this problem"); return -1; }
+        const int64_t slabs = pr.P <= 1 ? 0 : (int64_t)2 * pr.P * p->batch * p->n_groups * (int64_t)p->dstate * p->seqlen;
+        return (slabs + rowlane_summary_floats(p, pr.S)) * (int64_t)sizeof(float);
+    }
     if (p->ckpt_pitch == SIGMA_SCAN_CKPT_PITCH_160) {
         const Plan4 p4 = plan_bwd4(p, true);
         if (!p4.ok) { fail(SIGMA_ERR_BAD_SHAPE, "ckpt_pitch 160 (quad-row backward) is not available for this problem"); return -1; }
@@ -641,6 +754,45 @@ int sigma_selective_scan_bwd(const sigma_scan_bwd_params* q, void* stream) {
     if ((p->D == nullptr) != (q->dD == nullptr) || (p->delta_bias == nullptr) != (q->ddelta_bias == nullptr))
         return fail(SIGMA_ERR_NULL_ARG, "dD / ddelta_bias must be given exactly when D / delta_bias are");
     const bool vec = vec_ok_bwd(q);
+    if (q->dout_group_shift < 0 || q->dout_group_shift > 5)
+        return fail(SIGMA_ERR_BAD_SHAPE, "dout_group_shift must be in [0, 5] (got %d)", q->dout_group_shift);
+    if (p->ckpt_pitch == SIGMA_SCAN_CKPT_PITCH_16) {
+        const PlanR pr = plan_rowlane(p, vec, true);
+        if (!pr.ok)
+            return fail(SIGMA_ERR_BAD_SHAPE, "ckpt_pitch 16 needs f32 IO, 16-byte aligned operands, dstate in {4,8,16}, seqlen %% 4 == 0 and rows per group divisible by 64");
+        if (p->seqlen > SIGMA_SCAN_CKPT_PITCH_16 && !p->x)
+            return fail(SIGMA_ERR_NULL_ARG, "x (forward checkpoints) is required when seqlen > the checkpoint pitch");
+        const int64_t slab = pr.P > 1 ? (int64_t)pr.P * p->batch * p->n_groups * (int64_t)p->dstate * p->seqlen : 0;
+        const int64_t summ = rowlane_summary_floats(p, pr.S);
+        const int64_t need = (2 * slab + summ) * (int64_t)sizeof(float);
+        if (need > 0) {
+            if (!q->workspace || q->workspace_bytes < need)
+                return fail(SIGMA_ERR_NULL_ARG, "workspace of %lld bytes required (got %lld)", (long long)need, (long long)q->workspace_bytes);
+            if (!aligned_to(q->workspace, 16)) return fail(SIGMA_ERR_BAD_STRIDE, "workspace must be 16-byte aligned");
+        }
+        sigma::BwdArgs a;
+        std::memset(&a, 0, sizeof(a));
+        a.f = make_fwd_args(p, pr.NW, 1, p->dstate, vec);
+        a.dout = q->dout; a.du = q->du; a.ddelta = q->ddelta;
+        a.dA = q->dA; a.dB = q->dB; a.dC = q->dC; a.dD = q->dD; a.dbias = q->ddelta_bias;
+        a.g_bs = q->dout_batch_stride; a.g_ds = q->dout_d_stride;
+        a.du_bs = q->du_batch_stride; a.du_ds = q->du_d_stride;
+        a.dd_bs = q->ddelta_batch_stride; a.dd_ds = q->ddelta_d_stride;
+        a.dA_ds = q->dA_d_stride; a.dA_ns = q->dA_dstate_stride;
+        a.dB_bs = q->dB_batch_stride; a.dB_gs = q->dB_group_stride; a.dB_ns = q->dB_dstate_stride;
+        a.dC_bs = q->dC_batch_stride; a.dC_gs = q->dC_group_stride; a.dC_ns = q->dC_dstate_stride;
+        a.P = pr.P; a.S = pr.S; a.seg_tiles = pr.seg_tiles;
+        a.g_gshift = q->dout_group_shift;
+        a.out_vec_ok = (aligned_to(q->dB, 16) && aligned_to(q->dC, 16) && q->dB_batch_stride % 4 == 0 &&
+                        q->dB_group_stride % 4 == 0 && q->dB_dstate_stride % 4 == 0 && q->dC_batch_stride % 4 == 0 &&
+                        q->dC_group_stride % 4 == 0 && q->dC_dstate_stride % 4 == 0) ? 1 : 0;
+        a.ws_dB = pr.P > 1 ? static_cast<float*>(q->workspace) : nullptr;
+        a.ws_dC = pr.P > 1 ? static_cast<float*>(q->workspace) + slab : nullptr;
+        a.summ = summ > 0 ? static_cast<float*>(q->workspace) + 2 * slab : nullptr;
+        hipError_t e = sigma::launch_scan_bwdr(a, static_cast<hipStream_t>(stream));
+        if (e != hipSuccess) return fail(SIGMA_ERR_LAUNCH, "scan_bwdr launch failed: %s", hipGetErrorString(e));
+        return SIGMA_OK;
+    }
     Plan4 p4;
     std::memset(&p4, 0, sizeof(p4));
     if (p->ckpt_pitch == SIGMA_SCAN_CKPT_PITCH_160) {
@@ -714,6 +866,8 @@ int sigma_scan_debug_read(uint64_t out16[16]) {
     hipError_t e = hipDeviceSynchronize();
     if (e == hipSuccess) e = sigma::bwd2_prof_read(reinterpret_cast<unsigned long long*>(out16));
     if (e == hipSuccess && out16[15] == 0) e = sigma::bwd4_prof_read(reinterpret_cast<unsigned long long*>(out16));   // quad-row kernel ran
+    if (e == hipSuccess && out16[15] == 0) e = sigma::bwdr_prof_read(reinterpret_cast<unsigned long long*>(out16));   // row-lane backward ran
+    if (e == hipSuccess && out16[15] == 0) e = sigma::fwdr_prof_read(reinterpret_cast<unsigned long long*>(out16));   // row-lane forward ran
     if (e != hipSuccess) return fail(SIGMA_ERR_LAUNCH, "debug read failed: %s", hipGetErrorString(e));
     return SIGMA_OK;
 }

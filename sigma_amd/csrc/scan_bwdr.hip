@@ -1,0 +1,673 @@
+// scan_bwdr.hip -- selective-scan backward, "row-lane" mapping (gfx950 / MI355X, wave64, f32 IO, ckpt_pitch 16).
+//
+// Same operator as scan_bwd4.hip (reference: models/encoders/selective_scan/csrc/selective_scan/
+// selective_scan_bwd_kernel.cuh:66-308, reverse_scan.cuh:18-401; mathematics SURVEY.md App. E.2); the mapping is the one
+// of scan_fwdr.hip (scan_rowlane.h): a lane is a channel row, a wave is 64 rows x NS states, B / C are SGPR operands,
+// tiles of 16 positions, the state entering a tile comes from the forward's per-tile checkpoint.  Per element-state:
+//     forward replay   v_mul, v_exp, v_mul, v_fma                                   (a, x kept for the tile: 32 registers)
+//     reverse          v_fma (dx = g C + e), v_mul (e = a dx), v_fma (sum dx B), v_mul (t = e x_prev),
+//                      v_fma (sum A t), v_fma (dA), v_mul (dx delta u), v_mul (g x)
+// = 11 plain VALU + 1 v_exp, against 17.5 + 1.1 of the quad-row kernel's mathematics plus its mapping overhead (row
+// scans, broadcasts, slabs, column sums; profiles/r03_bwd4_issue_model.md: 1170 clocks per 640 element-states).  What
+// this mapping pays instead: the dB / dC terms of a (state, position) are spread over the 64 LANES of a wave.  They are
+// summed by a transpose-reduce network per state and tile: 32 registers (16 positions x {dB, dC}) -> 1 register in which
+// every lane pair holds the total of one slot: 24 lane swaps (v_permlane32_swap, v_permlane16_swap) + 24 adds + 15 DPP
+// adds + 1 select, ~20 clocks per 64 element-states.  The totals of a row block leave through the per-block slabs of the caller's
+// workspace (reduce_partials_kernel adds the blocks of a group in a fixed order: deterministic).
+//
+// Few rows: the sequence is cut into S segments; rev_summary (MODE 1 of the same body) writes per segment, row and state
+// (decay product P, reverse value E from zero), a segment composes the summaries to its right into its incoming carry.
+#include "scan_device.h"
+#include "scan_launch.h"
+#include "scan_rowlane.h"
+
+#include <atomic>
+#include <type_traits>
+
+// 1: u / delta / dout of the next tile travel by LDS-DMA (12 KB of LDS more: two workgroups per CU); 0: in registers
+#ifndef SIGMA_RL_DMA
+#define SIGMA_RL_DMA 1
+#endif
+
+#if SIGMA_RL_PROF
+__device__ unsigned long long g_bwdr_prof[16];
+#endif
+
+namespace sigma {
+
+#if SIGMA_RL_PROF
+hipError_t bwdr_prof_read(unsigned long long* out16) {
+    hipError_t e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_bwdr_prof), 16 * sizeof(unsigned long long));
+    if (e != hipSuccess) return e;
+    unsigned long long z[16] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_bwdr_prof), z, sizeof(z));
+}
+#else
+hipError_t bwdr_prof_read(unsigned long long* out16) { for (int i = 0; i < 16; ++i) out16[i] = 0; return hipSuccess; }
+#endif
+
+namespace {
+
+// a + b with the halves / rows regrouped (semantics pinned by tools/ubench/lane_ops_probe.hip, as scan_quad.h):
+//   swap32: lanes 0-31 of the result = a[0:32] + a[32:64], lanes 32-63 = b[0:32] + b[32:64]
+//   swap16: DPP rows of the result = {a.r0 + a.r1, b.r0 + b.r1, a.r2 + a.r3, b.r2 + b.r3}
+__device__ __forceinline__ float rl_fold32(float a, float b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+    return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+__device__ __forceinline__ float rl_fold16(float a, float b) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+    return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+
+// Sum of the dB / dC terms of a tile over the 64 lanes.  The 32 slots of a tile are (memory half hm, position j in the
+// half, array dB / dC).  rl_reduce_half takes the eight fold32(dB term, dC term) registers of ONE half (w[j]: lanes 0-31
+// = dB of position j summed over lane pairs l, l + 32; lanes 32-63 = dC) to ONE register in which every lane holds the sum
+// over 16 lanes of one slot; rl_reduce_finish merges the registers of the two halves: on return lane l holds the total of
+//     array  l >> 5,   memory position  8 * bit1(l) + 2 * bit2(l) + bit3(l) + 4 * bit4(l)       (each total in lanes l, l ^ 1).
+// Stages: halves of the wave (permlane32_swap: runs as soon as a position is done), row pairs (permlane16_swap: positions
+// j and j + 4), inside a DPP row distance 8 and 4 by DPP adds under bank masks (a disabled lane keeps what the other add
+// of the pair wrote), distance 2 by two quad permutes + one select, distance 1 by a quad permute.  The network was
+// checked lane by lane with a symbolic model (tools/rowlane_reduce_model.py prints the table above).
+// Hazard: a VALU write followed by a DPP read of the same VGPR needs two wait states.
+__device__ __forceinline__ float rl_reduce_half(const float (&w)[8]) {
+    const float z0 = rl_fold16(w[0], w[4]), z1 = rl_fold16(w[1], w[5]), z2 = rl_fold16(w[2], w[6]), z3 = rl_fold16(w[3], w[7]);
+    float q0, q1, ph;
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %3, %3 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %1, %5, %5 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+        "v_add_f32_dpp %0, %4, %4 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "v_add_f32_dpp %1, %6, %6 row_ror:8 row_mask:0xf bank_mask:0xc\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %2, %0, %0 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+        "v_add_f32_dpp %2, %1, %1 row_shr:4 row_mask:0xf bank_mask:0xa\n\t"
+        : "=&v"(q0), "=&v"(q1), "=&v"(ph)
+        : "v"(z0), "v"(z1), "v"(z2), "v"(z3));
+    return ph;
+}
+
+// p0 = rl_reduce_half of memory half 0, p1 = of memory half 1
+__device__ __forceinline__ float rl_reduce_finish(float p0, float p1) {
+    float t0, t1, o;
+    const unsigned long long lanes_bit1 = 0xCCCCCCCCCCCCCCCCull;
+    asm volatile(
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %0, %3, %3 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_add_f32_dpp %1, %4, %4 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+        "v_cndmask_b32 %2, %0, %1, %5\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %2, %2, %2 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+        : "=&v"(t0), "=&v"(t1), "=&v"(o)
+        : "v"(p0), "v"(p1), "s"(lanes_bit1));
+    return o;
+}
+
+typedef float v8f_a16 __attribute__((ext_vector_type(8), aligned(16)));
+typedef const __attribute__((address_space(4))) v8f_a16* cv8p_t;
+
+// B or C of one (state, half tile): 8 consecutive floats at a wave-uniform address -> SGPRs; nch = valid 16-byte chunks
+// of the half (2 except in a partial last tile), missing ones read as zero
+__device__ __forceinline__ void rl_load_bc8(const float* base, int nch, float (&v)[8]) {
+#if SIGMA_RL_ABL & 1
+    float c = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane((int)(reinterpret_cast<uintptr_t>(base) & 0xffff) | 0x3f000000));
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { v[k] = c; asm volatile("" : "+s"(c)); }
+    return;
+#endif
+    if (nch >= 2) {
+        const auto t = *reinterpret_cast<cv8p_t>(reinterpret_cast<uintptr_t>(base));
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = t[k];
+    } else {
+        const v4f z = {0.0f, 0.0f, 0.0f, 0.0f};
+        const v4f c0 = nch > 0 ? *reinterpret_cast<cv4p_t>(reinterpret_cast<uintptr_t>(base)) : z;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] = c0[j]; v[4 + j] = 0.0f; }
+    }
+}
+
+// 16 bytes of a row; `ok` false: zeros (the load itself always runs, from the row start, so that the VMEM operations of a
+// tile are the same on every path and the compiler's vmcnt bookkeeping stays exact instead of falling back to vmcnt(0))
+__device__ __forceinline__ v4f rl_load4u(const float* __restrict__ row, int off, bool ok) {
+    const v4f z = {0.0f, 0.0f, 0.0f, 0.0f};
+#if SIGMA_RL_ABL & 4
+    const float c = 0.001f * (float)((reinterpret_cast<uintptr_t>(row) + off) & 0xff);
+    const v4f t = {c, 0.5f * c, 0.25f * c, -c};
+    return ok ? t : z;
+#endif
+    const v4f t = *reinterpret_cast<const v4f*>(row + (ok ? off : 0));
+    return ok ? t : z;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The backward proper.  A workgroup is one block of 64 rows x 4 state waves (NS = dstate / 4 states each).  Per tile of 16
+// positions: the (row, chunk) threads pre-process u / delta / dout once (softplus, delta * u, softplus') into LDS; then
+// the tile is walked as TWO halves of 8 positions, second half in scan order first.  Per half every wave runs, for each of
+// its states: forward replay of the half from the forward's checkpoint (pitch 8), the reverse recurrence, the sums over
+// the states of dx B and A2 dx a x_prev in 16 registers, and the lane-reduce of the dB / dC terms.  Halves rather than
+// whole tiles keep the per-lane arrays at 8 entries (~120 VGPRs, 3-4 waves per SIMD) where whole tiles need > 200.
+template <int NS, bool REV>
+__device__ __forceinline__ void scan_bwdr_body(const BwdArgs& q, float* smem, int b, int g, int rbg, int seg) {
+    constexpr int T = kRT, H = kRT / 2;
+    const FwdArgs& p = q.f;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int sw = __builtin_amdgcn_readfirstlane(tid >> 6);      // state wave 0..3
+    const int N = p.N, L = p.L;
+    const int ntiles = (L + T - 1) / T;
+    v4f* sProc = reinterpret_cast<v4f*>(smem);                    // [5][4][64] float4: delta, delta * u, dout; u, softplus' (epilogue)
+    v4f* sEx = sProc + 5 * 256;                                   // [4 waves][2][4][64] float4: sum dx B, sum A2 dx a x_prev
+    v4f* sRaw = sEx + 8 * 256;                                    // [3][256 threads] float4: u, delta, dout of the NEXT tile (LDS-DMA)
+    const unsigned raw_base = (unsigned)(uintptr_t)(lptr_t)(sRaw + sw * 64);   // this wave's 1 KB of array 0
+
+    // thread as (row, chunk)
+    const int rr = (sw << 4) | (lane >> 2), cc = lane & 3;
+    const int rpg = p.rows_per_group;
+    const int row0 = g * rpg + rbg * kRRows;
+    const int r_rc = row0 + rr;
+    const int ur_rc = r_rc - ((g - (g >> p.u_gshift)) * rpg);     // same row of group g >> u_gshift
+    const int gr_rc = r_rc - ((g - (g >> q.g_gshift)) * rpg);
+    // rows of this thread as wave-uniform bases (the block's first row; SGPRs) + 32-bit element offsets (the row inside
+    // the block and the chunk): five 64-bit per-thread pointers less across the state loops (host: 64 rows x stride < 2^29)
+    const int ur0 = row0 - ((g - (g >> p.u_gshift)) * rpg), gr0 = row0 - ((g - (g >> q.g_gshift)) * rpg);
+    const float* u_blk = reinterpret_cast<const float*>(p.u) + (long)b * p.u_bs + (long)ur0 * p.u_ds;
+    const float* d_blk = reinterpret_cast<const float*>(p.delta) + (long)b * p.dt_bs + (long)row0 * p.dt_ds;
+    const float* g_blk = reinterpret_cast<const float*>(q.dout) + (long)b * q.g_bs + (long)gr0 * q.g_ds;
+    float* du_blk = reinterpret_cast<float*>(q.du) + (long)b * q.du_bs + (long)row0 * q.du_ds;
+    float* dd_blk = reinterpret_cast<float*>(q.ddelta) + (long)b * q.dd_bs + (long)row0 * q.dd_ds;
+    const int u_off = rr * (int)p.u_ds + 4 * cc, d_off = rr * (int)p.dt_ds + 4 * cc, g_off = rr * (int)q.g_ds + 4 * cc;
+    const int du_off = rr * (int)q.du_ds + 4 * cc, dd_off = rr * (int)q.dd_ds + 4 * cc;
+    (void)ur_rc; (void)gr_rc;
+    const int pr_rc = param_row(r_rc, g, rpg, p.pswap);
+    const float bias = p.bias ? p.bias[pr_rc] : 0.0f;
+    const float Dd = p.D ? p.D[pr_rc] : 0.0f;
+    float dD_acc = 0.0f, dbias_acc = 0.0f;
+
+    // thread as row lane
+    const int pr_ln = param_row(row0 + lane, g, rpg, p.pswap);
+    const int n0 = sw * NS;
+    float A2[NS], ecar[NS], dAacc[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        A2[s] = p.A[(long)pr_ln * p.A_ds + (long)(n0 + s) * p.A_ns] * kLog2e;
+        ecar[s] = 0.0f;
+        dAacc[s] = 0.0f;
+    }
+    const float* Bw = reinterpret_cast<const float*>(p.B) + (long)b * p.B_bs + (long)g * p.B_gs + (long)n0 * p.B_ns;
+    const float* Cw = reinterpret_cast<const float*>(p.C) + (long)b * p.C_bs + (long)g * p.C_gs + (long)n0 * p.C_ns;
+    const int B_ns = (int)p.B_ns, C_ns = (int)p.C_ns;               // host: (N - 1) * stride + L fits 31 bits
+    const long rowblock = (long)b * (p.dim >> 6) + (row0 >> 6);
+    // checkpoints: x[((rowblock * ntiles + tile) * 2 + h) * N + n) * 64 + lane], h = 0 after the first scan half of the tile
+    const float* ck = p.x + rowblock * ntiles * 2 * N * 64 + (long)n0 * 64;     // wave-uniform; + lane at the use
+
+    // dB / dC of this row block: the caller's tensors when the block is the whole group, else its slab of the workspace
+    float* __restrict__ oB;
+    float* __restrict__ oC;
+    long o_nsB, o_nsC;
+    if (q.P == 1) {
+        oB = q.dB + (long)b * q.dB_bs + (long)g * q.dB_gs; o_nsB = q.dB_ns;
+        oC = q.dC + (long)b * q.dC_bs + (long)g * q.dC_gs; o_nsC = q.dC_ns;
+    } else {
+        const long slab = (((long)rbg * p.batch + b) * p.G + g) * (long)N * L;
+        oB = q.ws_dB + slab; oC = q.ws_dC + slab; o_nsB = L; o_nsC = L;
+    }
+    // lane l of rl_reduce_finish: array l >> 5, memory position below (lanes l and l ^ 1 hold the same total and store it twice)
+    const int o_pos = ((lane >> 1) & 1) * 8 + ((lane >> 2) & 1) * 2 + ((lane >> 3) & 1) + ((lane >> 4) & 1) * 4;
+    float* __restrict__ o_lane = (lane < 32 ? oB + (long)n0 * o_nsB : oC + (long)n0 * o_nsC) + o_pos;
+    const int o_ns_lane = (int)(lane < 32 ? o_nsB : o_nsC);
+
+    // scan steps [st_lo, st_hi) of this workgroup, walked from the last to the first
+    const int st_lo = q.S > 1 ? seg * q.seg_tiles : 0;
+    const int st_hi = q.S > 1 ? (st_lo + q.seg_tiles < ntiles ? st_lo + q.seg_tiles : ntiles) : ntiles;
+    const int nst = st_hi - st_lo;
+    if (q.S > 1) {
+        // reverse carry entering the right end = composition of the summaries of the segments after this one
+        const float2* __restrict__ sm = reinterpret_cast<const float2*>(q.summ);
+        for (int t = q.S - 1; t > seg; --t) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const float2 pe = sm[(((long)(t - 1) * p.batch * (p.dim >> 6) + rowblock) * N + n0 + s) * 64 + lane];
+                ecar[s] = fmaf(pe.x, ecar[s], pe.y);
+            }
+        }
+    }
+    auto tile_of = [&](int st) { return REV ? (ntiles - 1 - st) : st; };   // memory tile of scan step st
+    // state entering scan half hs of scan step st: after the first half of the same tile / after the previous tile
+    // (before the first scan step there is no checkpoint: the load is clamped to a valid one and the caller scales by zero
+    // at the point of USE -- a select next to the load would make the compiler wait for it there)
+    auto ck_in = [&](int st, int hs, int s) {
+#if SIGMA_RL_ABL & 2
+        return 0.001f * st;
+#endif
+        const int tl = hs == 1 ? tile_of(st) : tile_of(st > 0 ? st - 1 : 0);
+        return ck[(unsigned)(((tl * 2 + (hs == 1 ? 0 : 1)) * N + s) * 64 + lane)];      // host: floats per row block < 2^31
+    };
+
+    // u / delta / dout of a tile travel by LDS-DMA one tile ahead (with register targets the compiler, short of
+    // registers, moved the requests next to their use: three exposed memory latencies per tile).  Chunks past the end of
+    // the row are requested at the row start (finite values) and masked when they are read back.
+    auto request = [&](int mt) {
+        const int tl = T * mt + 4 * cc < L ? T * mt : -4 * cc;      // past the end: the row start
+        rl_dma16s(u_blk, (unsigned)(u_off + tl) * 4u, raw_base);
+        rl_dma16s(d_blk, (unsigned)(d_off + tl) * 4u, raw_base + 256 * 16);
+        rl_dma16s(g_blk, (unsigned)(g_off + tl) * 4u, raw_base + 512 * 16);
+    };
+    int st = st_hi - 1;
+    int m = tile_of(st);
+#if SIGMA_RL_DMA
+    request(m);
+#else
+    v4f u_nx = rl_load4u(u_blk + u_off - 4 * cc, T * m + 4 * cc, T * m + 4 * cc < L);
+    v4f d_nx = rl_load4u(d_blk + d_off - 4 * cc, T * m + 4 * cc, T * m + 4 * cc < L);
+    v4f g_nx = rl_load4u(g_blk + g_off - 4 * cc, T * m + 4 * cc, T * m + 4 * cc < L);
+#endif
+    float x1_nx[NS];                                                // entering the second scan half of the next step
+#pragma unroll
+    for (int s = 0; s < NS; ++s) x1_nx[s] = ck_in(st, 1, s);
+    // B / C of the NEXT tile are pulled into L2 a tile ahead (see scan_fwdr.hip)
+    const float* __restrict__ bc_touch = ((lane & 1) ? Cw : Bw) + (long)((lane >> 1) & (NS - 1)) * ((lane & 1) ? C_ns : B_ns);
+    float touch_nx = 0.0f, touch_acc = 0.0f;
+    RLPROF_DECL
+
+    auto step = [&](int it, auto tail_tag) {
+        constexpr bool TAIL = decltype(tail_tag)::value;
+        st = st_hi - 1 - it;
+        m = tile_of(st);
+        const bool valid = !TAIL || T * m + 4 * cc < L;
+        const int nch = TAIL ? (L - T * m) >> 2 : 4;                // valid 16-byte chunks of this tile
+        const int hm_first = REV ? 0 : 1;                           // memory half of the second scan half (walked first)
+        float Bn[H], Cn[H];
+        rl_load_bc8(Bw + T * m + H * hm_first, nch - 2 * hm_first, Bn);      // first step's B / C: requested before anything waits
+        rl_load_bc8(Cw + T * m + H * hm_first, nch - 2 * hm_first, Cn);
+        __builtin_amdgcn_sched_barrier(0);
+#if SIGMA_RL_DMA
+        // This tile's u / delta / dout have landed.  A full step of the loop issues 3 + 2 NS vector-memory operations
+        // after its requests (the touch, NS checkpoint loads, NS dB/dC stores, du, ddelta), which stay in
+        // flight; the partial tile may skip some of them, so it (and the step after it: the caller waits) drains the counter.
+        if (TAIL) rl_dma_wait(); else rl_dma_wait_keep<3 + 2 * NS>();
+        const v4f uu = sRaw[tid], dd = sRaw[256 + tid];
+        v4f g4 = sRaw[512 + tid];
+        const v4f zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+        g4 = valid ? g4 : zero4;                                    // dout reads as zero past the end
+#else
+        const v4f uu = u_nx, dd = d_nx, g4 = g_nx;
+#endif
+        float x1[NS], x0[NS];
+        const float x0_scale = st > 0 ? 1.0f : 0.0f;
+        touch_acc += touch_nx;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) { x1[s] = x1_nx[s]; x0[s] = ck_in(st, 0, s); }     // x0: used half a tile from now
+        {                                                           // next tile's operands fly during this tile
+            const bool more = it + 1 < nst;
+            const int mn = tile_of(more ? st - 1 : st);
+#if SIGMA_RL_DMA
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the reads of this tile's bytes are done
+            request(mn);
+#else
+            u_nx = rl_load4u(u_blk + u_off - 4 * cc, T * mn + 4 * cc, more && T * mn + 4 * cc < L);
+            d_nx = rl_load4u(d_blk + d_off - 4 * cc, T * mn + 4 * cc, more && T * mn + 4 * cc < L);
+            g_nx = rl_load4u(g_blk + g_off - 4 * cc, T * mn + 4 * cc, more && T * mn + 4 * cc < L);
+#endif
+            touch_nx = bc_touch[T * mn];
+        }
+        {
+            v4f dl4, dlu4, sg4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float raw = dd[j] + bias;
+                float sig;
+#if SIGMA_RL_ABL & 32
+                const float sp = raw * raw; sig = 1.0f;
+#else
+                const float sp = softplus_ref(raw, sig);
+#endif
+                float d = p.softplus ? sp : raw;
+                sg4[j] = p.softplus ? sig : 1.0f;
+                d = valid ? d : 0.0f;                               // identity element past the end (a = 1, b = 0)
+                dl4[j] = d;
+                dlu4[j] = d * uu[j];
+                dD_acc = fmaf(g4[j], uu[j], dD_acc);
+            }
+            // the epilogue of this tile reads its operands back (they would cost 16 registers across the state loops)
+            sProc[rl_unit(cc, rr)] = dl4;
+            sProc[256 + rl_unit(cc, rr)] = dlu4;
+            sProc[512 + rl_unit(cc, rr)] = g4;
+            sProc[768 + rl_unit(cc, rr)] = uu;
+            sProc[1024 + rl_unit(cc, rr)] = sg4;
+        }
+        RLPROF(0)                                                   // operand wait, softplus, LDS writes
+        rl_barrier();
+        RLPROF(1)                                                   // barrier 1
+
+        float psave[NS];
+#pragma unroll
+        for (int hs = 1; hs >= 0; --hs) {
+            const int hm = REV ? 1 - hs : hs;                       // memory half
+            float dl[H], dlu[H], gg[H], sdxB[H], sAx[H];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const v4f a4 = sProc[rl_unit(2 * hm + c, lane)], b4 = sProc[256 + rl_unit(2 * hm + c, lane)];
+                const v4f g4r = sProc[512 + rl_unit(2 * hm + c, lane)];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    dl[4 * c + j] = a4[j]; dlu[4 * c + j] = b4[j]; gg[4 * c + j] = g4r[j];
+                    sdxB[4 * c + j] = 0.0f; sAx[4 * c + j] = 0.0f;
+                }
+            }
+            // LDS reads and scalar loads share one counter: retire the reads before the first scalar request of the state
+            // loop, or its wait for them (lgkmcnt(0)) would also sit out that request
+            asm volatile("" : "+v"(dl[0]), "+v"(dlu[0]), "+v"(gg[0]), "+v"(dl[4]), "+v"(dlu[4]), "+v"(gg[4]));
+            __builtin_amdgcn_sched_barrier(0);
+            RLPROF(2)                                               // LDS reads
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                float Bt[H], Ct[H];
+#pragma unroll
+                for (int k = 0; k < H; ++k) { Bt[k] = Bn[k]; Ct[k] = Cn[k]; }
+                // Scalar loads return out of order, so every wait on them is lgkmcnt(0): the operands of THIS step are
+                // waited for here, BEFORE the requests of the next step are issued -- which then have a whole step to arrive.
+                asm volatile("" : "+s"(Bt[0]), "+s"(Ct[0]));
+                __builtin_amdgcn_sched_barrier(0);
+                RLPROF(3)                                           // scalar operand wait
+                if (s + 1 < NS) {
+                    rl_load_bc8(Bw + (s + 1) * B_ns + T * m + H * hm, nch - 2 * hm, Bn);
+                    rl_load_bc8(Cw + (s + 1) * C_ns + T * m + H * hm, nch - 2 * hm, Cn);
+                } else if (hs == 1) {                               // first state of the other half
+                    rl_load_bc8(Bw + T * m + H * (1 - hm), nch - 2 * (1 - hm), Bn);
+                    rl_load_bc8(Cw + T * m + H * (1 - hm), nch - 2 * (1 - hm), Cn);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const float xin = hs == 1 ? x1[s] : x0[s] * x0_scale;
+                float a[H], xs[H];
+                // ---- forward replay from the checkpoint
+                {
+                    float x = xin;
+#pragma unroll
+                    for (int kk = 0; kk < H; ++kk) {
+                        const int k = REV ? H - 1 - kk : kk;
+                        a[k] = fast_exp2(dl[k] * A2[s]);
+                        x = fmaf(a[k], x, dlu[k] * Bt[k]);
+                        xs[k] = x;
+                    }
+                }
+                // ---- reverse: dx_k = g_k C_k + e_{k+1}, e_k = a_k dx_k
+                float e = ecar[s];
+                float w[H];
+#pragma unroll
+                for (int kk = H - 1; kk >= 0; --kk) {
+                    const int k = REV ? H - 1 - kk : kk;
+                    const float dx = fmaf(gg[k], Ct[k], e);
+                    e = a[k] * dx;
+                    const int kp = REV ? k + 1 : k - 1;             // previous position in scan order
+                    const float xprev = kk > 0 ? xs[kk > 0 ? kp : k] : xin;
+                    sdxB[k] = fmaf(dx, Bt[k], sdxB[k]);
+                    const float t = e * xprev;                      // dx * a_k * x_{k-1}
+                    sAx[k] = fmaf(A2[s], t, sAx[k]);                // x ln 2 in the epilogue
+                    dAacc[s] = fmaf(dl[k], t, dAacc[s]);
+                    // this row's terms of dB[n, l] and dC[n, l]: the two wave halves summed at once
+#if SIGMA_RL_ABL & 64
+                    w[k] = dx * dlu[k] + gg[k] * xs[k];
+#else
+                    w[k] = rl_fold32(dx * dlu[k], gg[k] * xs[k]);
+#endif
+                }
+                ecar[s] = e;
+#if SIGMA_RL_ABL & 64
+                const float ph = ((w[0] + w[1]) + (w[2] + w[3])) + ((w[4] + w[5]) + (w[6] + w[7]));
+#else
+                const float ph = rl_reduce_half(w);
+#endif
+                if (hs == 1) {
+                    psave[s] = ph;
+                } else {
+#if SIGMA_RL_ABL & 64
+                    const float tot = ph + psave[s];
+#else
+                    const float tot = hm == 0 ? rl_reduce_finish(ph, psave[s]) : rl_reduce_finish(psave[s], ph);
+#endif
+                    if (!TAIL || T * m + o_pos < L) o_lane[s * o_ns_lane + T * m] = tot;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                RLPROF(4)                                           // state loop
+            }
+            // ---- the sums over the states of the four waves meet in LDS
+#if SIGMA_RL_ABL & 16
+            asm volatile("" :: "v"(sdxB[0]), "v"(sdxB[5]), "v"(sAx[2]), "v"(sAx[7]));
+#else
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const v4f t1 = {sdxB[4 * c], sdxB[4 * c + 1], sdxB[4 * c + 2], sdxB[4 * c + 3]};
+                const v4f t2 = {sAx[4 * c], sAx[4 * c + 1], sAx[4 * c + 2], sAx[4 * c + 3]};
+                sEx[(sw * 2) * 256 + rl_unit(2 * hm + c, lane)] = t1;
+                sEx[(sw * 2 + 1) * 256 + rl_unit(2 * hm + c, lane)] = t2;
+            }
+#endif
+            if (hs == 1) {                                          // entering the second scan half of the NEXT step
+                const int stn = it + 1 < nst ? st - 1 : st;
+#pragma unroll
+                for (int s = 0; s < NS; ++s) x1_nx[s] = ck_in(stn, 1, s);
+            }
+            RLPROF(5)                                               // exchange writes
+        }
+        rl_barrier();
+        RLPROF(6)                                                   // barrier 2
+        {
+            v4f S1 = {0.0f, 0.0f, 0.0f, 0.0f}, S2 = {0.0f, 0.0f, 0.0f, 0.0f};
+#if !(SIGMA_RL_ABL & 16)
+#pragma unroll
+            for (int w = 0; w < 4; ++w) { S1 += sEx[(w * 2) * 256 + rl_unit(cc, rr)]; S2 += sEx[(w * 2 + 1) * 256 + rl_unit(cc, rr)]; }
+#endif
+            const v4f dle = sProc[rl_unit(cc, rr)], ge = sProc[512 + rl_unit(cc, rr)];
+            const v4f ue = sProc[768 + rl_unit(cc, rr)], sge = sProc[1024 + rl_unit(cc, rr)];
+            v4f duv, ddv;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                duv[j] = fmaf(Dd, ge[j], dle[j] * S1[j]);
+                ddv[j] = fmaf(ue[j], S1[j], S2[j] * kLn2) * sge[j];
+                dbias_acc += valid ? ddv[j] : 0.0f;
+            }
+            if (valid) {
+                *reinterpret_cast<v4f*>(du_blk + (unsigned)(du_off + T * m)) = duv;
+                *reinterpret_cast<v4f*>(dd_blk + (unsigned)(dd_off + T * m)) = ddv;
+            }
+        }
+        RLPROF(7)                                                   // epilogue
+    };
+    // The partial tile (fewer than 16 positions: the memory-last one) is the first step of a forward group and the last
+    // of a reversed one: it is peeled off the loop.  With both variants of the body inside ONE loop the register
+    // allocation of the whole loop doubled (254 instead of 128 VGPRs at 16 states).
+    const int tail_tile = (L % T) ? ntiles - 1 : -1;                // memory tile with fewer than 16 positions
+    int it0 = 0, it1 = nst;
+#if SIGMA_RL_DMA
+    rl_dma_wait();                                                  // the first requests: nothing younger behind them yet
+#endif
+    if (!REV && nst > 0 && tile_of(st_hi - 1) == tail_tile) {
+        step(0, std::true_type{});
+        it0 = 1;
+#if SIGMA_RL_DMA
+        rl_dma_wait();
+#endif
+    }
+    if (REV && nst > 0 && tile_of(st_lo) == tail_tile) it1 = nst - 1;
+    for (int it = it0; it < it1; ++it) step(it, std::false_type{});
+    if (it1 < nst) step(it1, std::true_type{});
+    RLPROF_FLUSH(g_bwdr_prof)
+    if (touch_acc == 1.2345678e-30f) du_blk[0] = touch_acc;        // keeps the touches alive (never true in practice)
+
+    // per-row results: one atomicAdd per (row, state) / row and workgroup (several workgroups only with segments)
+#pragma unroll
+    for (int s = 0; s < NS; ++s) atomicAdd(q.dA + (long)pr_ln * q.dA_ds + (long)(n0 + s) * q.dA_ns, dAacc[s]);
+    // the four chunk threads of a row are neighbouring lanes
+    dD_acc += dpp_take<0xB1, 0xF>(0.0f, dD_acc);                    // quad_perm [1,0,3,2]
+    dD_acc += dpp_take<0x4E, 0xF>(0.0f, dD_acc);                    // quad_perm [2,3,0,1]
+    dbias_acc += dpp_take<0xB1, 0xF>(0.0f, dbias_acc);
+    dbias_acc += dpp_take<0x4E, 0xF>(0.0f, dbias_acc);
+    if (cc == 0) {
+        if (q.dD) atomicAdd(q.dD + pr_rc, dD_acc);
+        if (q.dbias) atomicAdd(q.dbias + pr_rc, dbias_acc);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Reverse summaries of the sequence split: for segment seg = 1 .. S-1, row and state the pair (decay product P, reverse
+// value E with zero carry): e(left end of the segment) = E + P * e(right end).  The reverse recurrence only.
+template <int NS, bool REV>
+__device__ __forceinline__ void scan_bwdr_summary_body(const BwdArgs& q, float* smem, int b, int g, int rbg, int seg) {
+    constexpr int T = kRT;
+    const FwdArgs& p = q.f;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int sw = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int N = p.N, L = p.L;
+    const int ntiles = (L + T - 1) / T;
+    v4f* sProc = reinterpret_cast<v4f*>(smem);                    // [2][4][64] float4: delta, dout
+    const int rr = (sw << 4) | (lane >> 2), cc = lane & 3;
+    const int rpg = p.rows_per_group;
+    const int row0 = g * rpg + rbg * kRRows;
+    const int r_rc = row0 + rr;
+    const int gr_rc = r_rc - ((g - (g >> q.g_gshift)) * rpg);
+    const float* __restrict__ d_row = reinterpret_cast<const float*>(p.delta) + (long)b * p.dt_bs + (long)r_rc * p.dt_ds;
+    const float* __restrict__ g_row = reinterpret_cast<const float*>(q.dout) + (long)b * q.g_bs + (long)gr_rc * q.g_ds;
+    const int pr_rc = param_row(r_rc, g, rpg, p.pswap);
+    const float bias = p.bias ? p.bias[pr_rc] : 0.0f;
+    const int pr_ln = param_row(row0 + lane, g, rpg, p.pswap);
+    const int n0 = sw * NS;
+    float A2[NS], ecar[NS], Pacc[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        A2[s] = p.A[(long)pr_ln * p.A_ds + (long)(n0 + s) * p.A_ns] * kLog2e;
+        ecar[s] = 0.0f;
+        Pacc[s] = 0.0f;                                             // log2 of the decay product
+    }
+    const float* Cw = reinterpret_cast<const float*>(p.C) + (long)b * p.C_bs + (long)g * p.C_gs + (long)n0 * p.C_ns;
+    const int C_ns = (int)p.C_ns;
+    const long rowblock = (long)b * (p.dim >> 6) + (row0 >> 6);
+    const int st_lo = seg * q.seg_tiles;
+    const int st_hi = st_lo + q.seg_tiles < ntiles ? st_lo + q.seg_tiles : ntiles;
+    const int nst = st_hi - st_lo;
+    auto tile_of = [&](int st) { return REV ? (ntiles - 1 - st) : st; };
+    int m = tile_of(st_hi - 1);
+    v4f d_nx = rl_load4u(d_row, T * m + 4 * cc, T * m + 4 * cc < L);
+    v4f g_nx = rl_load4u(g_row, T * m + 4 * cc, T * m + 4 * cc < L);
+    for (int it = 0; it < nst; ++it) {
+        const int st = st_hi - 1 - it;
+        m = tile_of(st);
+        const bool valid = T * m + 4 * cc < L;
+        const v4f dd = d_nx, g4 = g_nx;
+        {
+            const bool more = it + 1 < nst;
+            const int mn = tile_of(more ? st - 1 : st);
+            d_nx = rl_load4u(d_row, T * mn + 4 * cc, more && T * mn + 4 * cc < L);
+            g_nx = rl_load4u(g_row, T * mn + 4 * cc, more && T * mn + 4 * cc < L);
+        }
+        const int nch = (L - T * m) >= T ? 4 : (L - T * m) >> 2;
+        v4f dl4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float raw = dd[j] + bias;
+            float sig;
+            const float sp = softplus_ref(raw, sig);
+            const float d = p.softplus ? sp : raw;
+            dl4[j] = valid ? d : 0.0f;
+        }
+        sProc[rl_unit(cc, rr)] = dl4;
+        sProc[256 + rl_unit(cc, rr)] = g4;
+        rl_barrier();
+        float dl[T], gg[T];
+        float dsum = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const v4f a4 = sProc[rl_unit(c, lane)], g4r = sProc[256 + rl_unit(c, lane)];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { dl[4 * c + j] = a4[j]; gg[4 * c + j] = g4r[j]; dsum += a4[j]; }
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            float Ct[T];
+            rl_load_bc(Cw + s * C_ns + T * m, nch, Ct);
+            float e = ecar[s];
+#pragma unroll
+            for (int kk = T - 1; kk >= 0; --kk) {
+                const int k = REV ? T - 1 - kk : kk;
+                e = fast_exp2(dl[k] * A2[s]) * fmaf(gg[k], Ct[k], e);
+            }
+            ecar[s] = e;
+            Pacc[s] = fmaf(dsum, A2[s], Pacc[s]);
+        }
+        rl_barrier();
+    }
+    float2* __restrict__ sm = reinterpret_cast<float2*>(q.summ);
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+        sm[(((long)(seg - 1) * p.batch * (p.dim >> 6) + rowblock) * N + n0 + s) * 64 + lane] = make_float2(fast_exp2(Pacc[s]), ecar[s]);
+}
+
+// MODE 0: the backward proper; MODE 1: the summaries of segments 1 .. S-1
+template <int NS, int MODE>
+__global__ void __launch_bounds__(256, MODE == 1 ? 4 : 3)
+scan_bwdr_kernel(const BwdArgs q) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int lb = xcd_logical_block(blockIdx.x, gridDim.x);
+    const int S = MODE == 1 ? q.S - 1 : q.S;
+    const int PS = q.P * S;                                   // workgroups per (batch, group): row blocks x segments
+    const int per_b = q.f.G * PS;
+    const int b = lb / per_b;
+    const int rem = lb - b * per_b;
+    const int g = rem / PS;
+    const int rem2 = rem - g * PS;
+    const int rbg = rem2 / S;
+    const int seg = rem2 - rbg * S + (MODE == 1 ? 1 : 0);
+    const bool rev = (q.f.rev_mask >> g) & 1u;
+    if (MODE == 1) {
+        if (rev) scan_bwdr_summary_body<NS, true>(q, smem, b, g, rbg, seg);
+        else scan_bwdr_summary_body<NS, false>(q, smem, b, g, rbg, seg);
+    } else {
+        if (rev) scan_bwdr_body<NS, true>(q, smem, b, g, rbg, seg);
+        else scan_bwdr_body<NS, false>(q, smem, b, g, rbg, seg);
+    }
+}
+
+template <int NS, int MODE>
+static hipError_t launch_bwdr_t(const BwdArgs& a, hipStream_t stream) {
+    const int S = MODE == 1 ? a.S - 1 : a.S;
+    const int grid = a.f.batch * a.f.G * a.P * S;
+    const size_t lds = bwdr_lds_bytes(4);
+    auto kern = scan_bwdr_kernel<NS, MODE>;
+    static std::atomic<size_t> lds_cap[kMaxDevices];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= kMaxDevices) dev = 0;
+    if (lds > 48 * 1024 && lds > lds_cap[dev].load(std::memory_order_relaxed)) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        lds_cap[dev].store(lds, std::memory_order_relaxed);
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, a);
+    return hipGetLastError();
+}
+
+template <int MODE>
+static hipError_t launch_bwdr_ns(const BwdArgs& a, hipStream_t stream) {
+    switch (a.f.N) {
+        case 16: return launch_bwdr_t<4, MODE>(a, stream);
+        case 8: return launch_bwdr_t<2, MODE>(a, stream);
+        case 4: return launch_bwdr_t<1, MODE>(a, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+// a.P = 64-row blocks per (batch, group); a.S segments of a.seg_tiles tiles (a.summ when S > 1)
+hipError_t launch_scan_bwdr(const BwdArgs& a, hipStream_t stream) {
+    if (a.S > 1) {
+        hipError_t e = launch_bwdr_ns<1>(a, stream);
+        if (e != hipSuccess) return e;
+    }
+    hipError_t e = launch_bwdr_ns<0>(a, stream);
+    if (e != hipSuccess || a.P == 1) return e;
+    return launch_reduce_partials(a, stream);
+}
+
+}  // namespace sigma

@@ -499,6 +499,10 @@ struct FwdArgs {
     long x_rs;            // floats per row of x: checkpoint j of row (b, r) at x[(b*dim + r)*x_rs + j*N + n]
     long u_bs, u_ds, dt_bs, dt_ds, A_ds, A_ns;
     long B_bs, B_gs, B_ns, C_bs, C_gs, C_ns, o_bs, o_ds;
+    // row-lane forward (scan_fwdr.hip), few rows: the sequence in `segs` segments of `seg_tiles` 16-position tiles;
+    // fsumm = [(segs-1)][batch * dim/64][N][64 lanes][2] forward summaries (decay product, end state from zero)
+    int segs, seg_tiles;
+    float* fsumm;
 };
 
 struct BwdArgs {

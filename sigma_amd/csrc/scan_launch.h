@@ -51,14 +51,23 @@ inline size_t bwd4_lds_bytes(int W, int N, int SB, int RB, int nbuf = 2) {
 // scan_fwd4 (quad-row forward): two B/C images of one 160-tile for all states [2][2][N][160]
 inline size_t fwd4_lds_bytes(int N) { return sizeof(float) * (2 * 2 * (size_t)N * 160); }
 
+// row-lane kernels (scan_fwdr.hip / scan_bwdr.hip): [arrays][4 chunks][64 rows] float4 of pre-processed operands +
+// [state waves][...] partial sums over the states
+inline size_t fwdr_lds_bytes(int NW) { return 16 * (size_t)(2 * 256 + NW * 256); }
+inline size_t bwdr_lds_bytes(int NW) { return 16 * (size_t)(5 * 256 + NW * 2 * 256 + 3 * 256); }
+
 constexpr int kMaxDevices = 16;    // per-device cache of the raised dynamic-LDS cap (hipFuncSetAttribute is per device)
 
 hipError_t launch_scan_bwd2(const BwdArgs& a, int dtype, int T, bool glds, hipStream_t stream);
 hipError_t launch_scan_bwd3(const BwdArgs& a, int dtype, bool glds, hipStream_t stream);   // a.f.R = waves per workgroup
 hipError_t launch_scan_fwd4(const FwdArgs& a, hipStream_t stream);   // a.R = waves (4 rows each), a.rowblocks = workgroups per (batch, group)
 hipError_t launch_scan_bwd4(const BwdArgs& a, hipStream_t stream);   // a.f.R = waves (4 rows each), a.slab2 = states per barrier
+hipError_t launch_scan_fwdr(const FwdArgs& a, hipStream_t stream);   // a.rowblocks = 64-row blocks per (batch, group); a.segs / a.seg_tiles / a.fsumm
+hipError_t launch_scan_bwdr(const BwdArgs& a, hipStream_t stream);   // a.P = 64-row blocks per (batch, group); a.S / a.seg_tiles / a.summ
 hipError_t launch_reduce_partials(const BwdArgs& a, hipStream_t stream);
 hipError_t bwd4_prof_read(unsigned long long* out16);
+hipError_t fwdr_prof_read(unsigned long long* out16);     // development builds (SIGMA_RL_PROF), zeros otherwise
+hipError_t bwdr_prof_read(unsigned long long* out16);
 hipError_t bwd2_prof_read(unsigned long long* out16);     // development builds (SIGMA_BWD2_PROF), zeros otherwise
 hipError_t launch_scan_fwd(const FwdArgs& a, int dtype, int T, bool glds, bool prefetch, hipStream_t stream);
 hipError_t launch_scan_bwd(const BwdArgs& a, int dtype, int T, bool glds, hipStream_t stream);

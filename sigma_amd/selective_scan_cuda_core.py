@@ -106,6 +106,37 @@ def quad_backward_ok(u, delta, B, C) -> bool:
     return True
 
 
+def rowlane_ok(u, delta, B, C, dout=None) -> bool:
+    """True when the row-lane kernels (csrc/scan_fwdr.hip / scan_bwdr.hip, ckpt_pitch 16) can take these operands: f32 IO,
+    dstate in {4, 8, 16}, rows per group divisible by 64, L % 4 == 0, 16-byte aligned u / delta / B / C (/ dout) with
+    strides that are multiples of 4 elements (rowlane_legal in csrc/capi.hip is the authority and fails loudly)."""
+    if any(t.dtype != torch.float32 for t in (u, delta, B, C)):
+        return False
+    Bv = B if B.dim() == 4 else B.unsqueeze(1)
+    Cv = C if C.dim() == 4 else C.unsqueeze(1)
+    n_groups, dstate, seqlen = Bv.shape[1], Bv.shape[2], Bv.shape[3]
+    if dstate not in (4, 8, 16) or seqlen % 4 != 0 or seqlen == 0 or delta.shape[1] % (64 * n_groups) != 0:
+        return False
+    for t in (u, delta, Bv, Cv) + ((dout,) if dout is not None else ()):
+        if t.data_ptr() % 16 != 0 or t.stride(-1) != 1 or any(s % 4 != 0 for s in t.stride()[:-1]):
+            return False
+    if dstate * max(Bv.stride(2), Cv.stride(2)) + seqlen >= (1 << 29):
+        return False
+    return True
+
+
+_FINE_PITCHES = (_capi.SIGMA_SCAN_CKPT_PITCH_FINE, _capi.SIGMA_SCAN_CKPT_PITCH_320, _capi.SIGMA_SCAN_CKPT_PITCH_160,
+                 _capi.SIGMA_SCAN_CKPT_PITCH_16)
+
+
+def _ckpt_slots(seqlen: int, pitch: int) -> int:
+    """checkpoints per row of a fine-checkpoint x: one per `pitch` positions; pitch 16 (row-lane kernels): two per
+    16-position tile (include/sigma_scan.h)"""
+    if pitch == _capi.SIGMA_SCAN_CKPT_PITCH_16:
+        return 2 * max((seqlen + 15) // 16, 1)
+    return max((seqlen + pitch - 1) // pitch, 1)
+
+
 def _fine_pitch(x, seqlen: int, dstate: int, ckpt_pitch: int) -> int:
     """Pitch of a fine-checkpoint x (B, dim, ceil(L/pitch) * N): the caller's ``ckpt_pitch`` if given, else
     inferred from the slot count -- which is only possible when exactly one pitch of {640, 320, 160} gives
@@ -113,12 +144,11 @@ def _fine_pitch(x, seqlen: int, dstate: int, ckpt_pitch: int) -> int:
     if ckpt_pitch:
         return int(ckpt_pitch)
     slots = x.size(2) // max(dstate, 1)
-    match = [pitch for pitch in (_capi.SIGMA_SCAN_CKPT_PITCH_FINE, _capi.SIGMA_SCAN_CKPT_PITCH_320, _capi.SIGMA_SCAN_CKPT_PITCH_160)
-             if slots == max((seqlen + pitch - 1) // pitch, 1)]
+    match = [pitch for pitch in _FINE_PITCHES if slots == _ckpt_slots(seqlen, pitch)]
     if len(match) == 1:
         return match[0]
     if not match:
-        raise RuntimeError("fine-checkpoint x must be (batch, dim, ceil(L/pitch)*dstate) with pitch 640, 320 or 160")
+        raise RuntimeError("fine-checkpoint x must be (batch, dim, ceil(L/pitch)*dstate) with pitch 640, 320, 160 or 16")
     raise RuntimeError(f"fine-checkpoint x with {slots} slot(s) fits the pitches {match}: pass ckpt_pitch (the pitch given to fwd_ext)")
 
 
@@ -129,6 +159,8 @@ def _fill_fwd(fp: _capi.FwdParams, u, delta, A, B, C, D_, delta_bias_, out, x, d
     fp.param_group_swap = int(param_swap)
     if x is not None and x.dim() == 3:              # fine checkpoints: (B, dim, ceil(L/pitch) * N)
         fp.ckpt_pitch, fp.x_row_stride = _fine_pitch(x, seqlen, dstate, ckpt_pitch), x.stride(1)
+        if fp.ckpt_pitch == _capi.SIGMA_SCAN_CKPT_PITCH_16 and not x.is_contiguous():
+            raise RuntimeError("ckpt_pitch 16: x must be contiguous (its layout is private to the row-lane kernels)")
     elif x is None and ckpt_pitch:                  # inference: no checkpoints are written, the pitch still selects the kernel
         fp.ckpt_pitch = int(ckpt_pitch)
     fp.batch, fp.dim, fp.seqlen, fp.dstate, fp.n_groups = batch, dim, seqlen, dstate, n_groups
@@ -175,13 +207,11 @@ def fwd_ext(u, delta, A, B, C, D_, delta_bias_, delta_softplus, nrows: int = 1, 
     out = torch.empty_like(delta)                                   # selective_scan.cpp:226
     if fine_ckpt and not ckpt_pitch:
         ckpt_pitch = _capi.SIGMA_SCAN_CKPT_PITCH_FINE
-    _check(ckpt_pitch in (0, _capi.SIGMA_SCAN_CKPT_PITCH_FINE, _capi.SIGMA_SCAN_CKPT_PITCH_320, _capi.SIGMA_SCAN_CKPT_PITCH_160),
-           "ckpt_pitch must be 0, 640, 320 or 160")
+    _check(ckpt_pitch in (0,) + _FINE_PITCHES, "ckpt_pitch must be 0, 640, 320, 160 or 16")
     if not need_x:                                                  # eval / no_grad: nothing is checkpointed
         x = torch.empty((0,), device=u.device, dtype=torch.float32)
     elif ckpt_pitch:
-        ncp = (seqlen + ckpt_pitch - 1) // ckpt_pitch
-        x = torch.empty((batch, dim, max(ncp, 1) * dstate), device=u.device, dtype=torch.float32)
+        x = torch.empty((batch, dim, _ckpt_slots(seqlen, ckpt_pitch) * dstate), device=u.device, dtype=torch.float32)
     else:
         x = torch.empty((batch, dim, n_chunks, dstate * 2), device=u.device, dtype=torch.float32)  # :228
     if batch == 0 or seqlen == 0:
@@ -189,6 +219,13 @@ def fwd_ext(u, delta, A, B, C, D_, delta_bias_, delta_softplus, nrows: int = 1, 
     fp = _capi.FwdParams()
     _fill_fwd(fp, u, delta, A, B, C, D_, delta_bias_, out, x if need_x else None, delta_softplus, sizes,
               rev_mask, u_gshift, ckpt_pitch, param_swap)
+    workspace = None
+    if ckpt_pitch == _capi.SIGMA_SCAN_CKPT_PITCH_16:                # few rows: forward summaries of the sequence segments
+        ws_bytes = int(lib.sigma_scan_fwd_workspace_bytes(ctypes.byref(fp)))
+        _check(ws_bytes >= 0, "selective_scan_fwd: " + _capi.last_error())
+        if ws_bytes > 0:
+            workspace = torch.empty(ws_bytes, dtype=torch.uint8, device=u.device)
+            fp.workspace, fp.workspace_bytes = _ptr(workspace), ws_bytes
     with torch.cuda.device(u.device):                               # CUDAGuard, :240
         stream = torch.cuda.current_stream(u.device).cuda_stream    # :241
         key = (batch, dim, seqlen, dstate, sizes[4], u.element_size())
@@ -225,8 +262,7 @@ def bwd_ext(u, delta, A, B, C, D_, delta_bias_, dout, x_, delta_softplus, nrows:
         _check(x_.dtype == torch.float32 and x_.is_cuda and x_.is_contiguous(), "x must be a contiguous float32 GPU tensor")
         if x_.dim() == 3:        # fine checkpoints of fwd_ext(fine_ckpt=True / ckpt_pitch=...)
             pitch = _fine_pitch(x_, seqlen, dstate, ckpt_pitch)
-            ncp = (seqlen + pitch - 1) // pitch
-            _check(tuple(x_.shape) == (batch, dim, max(ncp, 1) * dstate), "fine-checkpoint x must be (batch, dim, ceil(L/pitch)*dstate)")
+            _check(tuple(x_.shape) == (batch, dim, _ckpt_slots(seqlen, pitch) * dstate), "fine-checkpoint x must be (batch, dim, ceil(L/pitch)*dstate)")
         else:
             _check(tuple(x_.shape) == (batch, dim, n_chunks, 2 * dstate),
                    "x must have shape (batch_size, dim, n_chunks, 2 * dstate)")

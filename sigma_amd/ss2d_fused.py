@@ -49,7 +49,7 @@ import os as _os
 _CKPT_ENV = _os.environ.get("SIGMA_CKPT_PITCH", "auto")
 
 
-def ckpt_pitch_for(seqlen: int, dstate: int = 16, rows: int = 0, quad_ok: bool = False) -> int:
+def ckpt_pitch_for(seqlen: int, dstate: int = 16, rows: int = 0, quad_ok: bool = False, rowlane_ok: bool = False) -> int:
     """Checkpoint pitch = backward tile length (include/sigma_scan.h).  Measured on MI355X
     (profiles/r02_bwd_plans.txt, profiles/r02_bwd4_shapes.txt):
       * 160 (quad-row backward, csrc/scan_bwd4.hip; ``quad_ok`` = selective_scan_cuda_core.quad_backward_ok of the
@@ -64,7 +64,7 @@ def ckpt_pitch_for(seqlen: int, dstate: int = 16, rows: int = 0, quad_ok: bool =
       * 640 otherwise."""
     if _CKPT_ENV != "auto":
         forced = int(_CKPT_ENV)
-        if forced != 160 or quad_ok:
+        if (forced != 160 or quad_ok) and (forced != 16 or rowlane_ok):
             return forced
     if quad_ok and ((dstate >= 8 and rows >= 8192) or (rows >= 12288 and seqlen <= 4800)):
         return 160

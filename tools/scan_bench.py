@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--fine", action="store_true", help="one checkpoint per backward tile with the pitch the fused model "
                     "path picks for the shape (sigma_amd.ss2d_fused.ckpt_pitch_for): the launches of the training step")
     ap.add_argument("--opt", action="append", default=[], help="library option name=value (sigma_scan_set_option), repeatable")
+    ap.add_argument("--pitch", type=int, default=0, help="force this checkpoint pitch (with --fine): 16 = row-lane kernels, 160 = quad-row")
     a = ap.parse_args()
     for kv in a.opt:
         k, v = kv.split("=")
@@ -111,7 +112,8 @@ def main():
         pitch = 0
         if a.fine:
             from sigma_amd.ss2d_fused import ckpt_pitch_for
-            pitch = ckpt_pitch_for(shape[2], shape[3], shape[0] * shape[1], core.quad_backward_ok(u, delta, Bm, Cm))
+            pitch = a.pitch or ckpt_pitch_for(shape[2], shape[3], shape[0] * shape[1], core.quad_backward_ok(u, delta, Bm, Cm),
+                                              core.rowlane_ok(u, delta, Bm, Cm))
             _, x = core.fwd_ext(u, delta, A, Bm, Cm, D, bias, True, ckpt_pitch=pitch)
         else:
             _, x = core.fwd(u, delta, A, Bm, Cm, D, bias, True, 1)
