@@ -213,6 +213,9 @@ int sigma_scan_abi_version(void);
  *   "bwd_wgs"                  quad-row backward: 2 = two workgroups of <= 8 waves per CU (A/B knob)
  *   "rl_waves"                 row-lane kernels (ckpt_pitch 16): state waves per 64-row block {4, 8, 16}; 0 = cost model
  *   "rl_segs"                  row-lane kernels: sequence segments (1 = never split, 2..64); 0 = cost model
+ *   "rl_chain"                 row-lane backward: chained walk (row blocks laid end to end over exactly as many workgroups as
+ *                              the chip holds, a cut row block hands its reverse carry to the neighbour): 2 = whenever
+ *                              there are more row blocks than resident workgroups; 0 / 1 = never (measured: no gain)
  * Returns SIGMA_ERR_BAD_OPTION for unknown names / unsupported values. */
 int sigma_scan_set_option(const char *name, int value);
 int sigma_scan_get_option(const char *name);

@@ -21,7 +21,7 @@ thread_local std::string g_err;
 std::atomic<int> g_opt_fwd_items{0}, g_opt_fwd_waves{0}, g_opt_fwd_tiles{0}, g_opt_fwd_nb{0};
 std::atomic<int> g_opt_bwd_items{0}, g_opt_bwd_waves{0}, g_opt_bwd_nb{0}, g_opt_no_glds{0}, g_opt_bwd_slab2{0}, g_opt_fwd_prefetch{0};
 std::atomic<int> g_opt_bwd_gen{0}, g_opt_bwd_rb{0}, g_opt_bwd_touch{0}, g_opt_bwd_sb{0}, g_opt_bwd_wgs{0}, g_opt_fwd_gen{0}, g_opt_bwd_seg{0};
-std::atomic<int> g_opt_rl_waves{0}, g_opt_rl_segs{0};
+std::atomic<int> g_opt_rl_waves{0}, g_opt_rl_segs{0}, g_opt_rl_chain{0};
 
 int fail(int code, const char* fmt, ...) {
     char buf[512];
@@ -542,6 +542,30 @@ int64_t rowlane_summary_floats(const sigma_scan_fwd_params* p, int S) {
     return S > 1 ? (int64_t)(S - 1) * p->batch * p->dim * (int64_t)p->dstate * 2 : 0;
 }
 
+// chained walk of the row-lane backward: hand-over slots [row blocks][N][64] floats + one flag per row block (reserved
+// for every row-lane backward, so that the workspace size does not depend on the device's occupancy answer)
+int64_t rowlane_chain_floats(const sigma_scan_fwd_params* p) {
+    const int64_t nrb = (int64_t)p->batch * (p->dim / 64);
+    return nrb * p->dstate * 64 + ((nrb + 3) / 4) * 4;
+}
+
+// tiles per workgroup of the chained walk, or 0: used when the row blocks do not fill whole rounds of resident
+// workgroups (768 blocks on 512 slots = two rounds, the second half empty: 1.5 rounds' worth of work in the time of 2)
+int rowlane_chain_tiles(const sigma_scan_fwd_params* p, const PlanR& pr) {
+    const int mode = g_opt_rl_chain.load();
+    // measured (profiles/r04_rowlane_chain.txt): (16,3072,1200,N16) 800 us chained against 779 us in 1.5 plain rounds --
+    // the kernel is bound by the issue rate of a SIMD, and the workgroups of a half-empty last round simply run faster;
+    // the walk is kept for launches that are latency-bound per wave, on request only
+    if (mode != 2 || pr.S != 1) return 0;
+    const long nrb = (long)p->batch * p->n_groups * pr.P;
+    const int ntiles = (p->seqlen + 15) / 16;
+    const long cap = (long)kCUs * sigma::bwdr_resident_per_cu(p->dstate);
+    if (nrb <= cap || nrb * ntiles >= (1L << 31)) return 0;
+    const long rounds = (nrb + cap - 1) / cap;
+    (void)rounds;
+    return (int)((nrb * ntiles + cap - 1) / cap);
+}
+
 }  // namespace
 
 extern "C" {
@@ -572,6 +596,7 @@ OptDesc g_opts[] = {
     {"bwd_rb", &g_opt_bwd_rb, {-3}},                       // scan_bwd2: row blocks per workgroup, 0..256
     {"rl_waves", &g_opt_rl_waves, {0, 4, 8, 16, -1}},       // row-lane kernels: state waves per 64-row block
     {"rl_segs", &g_opt_rl_segs, {-4}},                      // row-lane kernels: sequence segments, 0..64
+    {"rl_chain", &g_opt_rl_chain, {0, 1, 2, -1}},           // row-lane backward: chained walk 1 = never, 2 = whenever legal
 };
 }  // namespace
 
@@ -720,7 +745,7 @@ int64_t sigma_scan_bwd_workspace_bytes(const sigma_scan_bwd_params* q) {
         const PlanR pr = plan_rowlane(p, true, true);
         if (!pr.ok) { fail(SIGMA_ERR_BAD_SHAPE, "ckpt_pitch 16 (row-lane kernels) is not available for this problem"); return -1; }
         const int64_t slabs = pr.P <= 1 ? 0 : (int64_t)2 * pr.P * p->batch * p->n_groups * (int64_t)p->dstate * p->seqlen;
-        return (slabs + rowlane_summary_floats(p, pr.S)) * (int64_t)sizeof(float);
+        return (slabs + rowlane_summary_floats(p, pr.S) + rowlane_chain_floats(p)) * (int64_t)sizeof(float);
     }
     if (p->ckpt_pitch == SIGMA_SCAN_CKPT_PITCH_160) {
         const Plan4 p4 = plan_bwd4(p, true);
@@ -764,7 +789,7 @@ int sigma_selective_scan_bwd(const sigma_scan_bwd_params* q, void* stream) {
             return fail(SIGMA_ERR_NULL_ARG, "x (forward checkpoints) is required when seqlen > the checkpoint pitch");
         const int64_t slab = pr.P > 1 ? (int64_t)pr.P * p->batch * p->n_groups * (int64_t)p->dstate * p->seqlen : 0;
         const int64_t summ = rowlane_summary_floats(p, pr.S);
-        const int64_t need = (2 * slab + summ) * (int64_t)sizeof(float);
+        const int64_t need = (2 * slab + summ + rowlane_chain_floats(p)) * (int64_t)sizeof(float);
         if (need > 0) {
             if (!q->workspace || q->workspace_bytes < need)
                 return fail(SIGMA_ERR_NULL_ARG, "workspace of %lld bytes required (got %lld)", (long long)need, (long long)q->workspace_bytes);
@@ -789,6 +814,9 @@ int sigma_selective_scan_bwd(const sigma_scan_bwd_params* q, void* stream) {
         a.ws_dB = pr.P > 1 ? static_cast<float*>(q->workspace) : nullptr;
         a.ws_dC = pr.P > 1 ? static_cast<float*>(q->workspace) + slab : nullptr;
         a.summ = summ > 0 ? static_cast<float*>(q->workspace) + 2 * slab : nullptr;
+        a.chain_W = rowlane_chain_tiles(p, pr);
+        a.chain_carry = static_cast<float*>(q->workspace) + 2 * slab + summ;
+        a.chain_flag = reinterpret_cast<int*>(a.chain_carry + (int64_t)p->batch * (p->dim / 64) * p->dstate * 64);
         hipError_t e = sigma::launch_scan_bwdr(a, static_cast<hipStream_t>(stream));
         if (e != hipSuccess) return fail(SIGMA_ERR_LAUNCH, "scan_bwdr launch failed: %s", hipGetErrorString(e));
         return SIGMA_OK;

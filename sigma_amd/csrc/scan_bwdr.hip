@@ -149,9 +149,18 @@ __device__ __forceinline__ v4f rl_load4u(const float* __restrict__ row, int off,
 // its states: forward replay of the half from the forward's checkpoint (pitch 8), the reverse recurrence, the sums over
 // the states of dx B and A2 dx a x_prev in 16 registers, and the lane-reduce of the dB / dC terms.  Halves rather than
 // whole tiles keep the per-lane arrays at 8 entries (~120 VGPRs, 3-4 waves per SIMD) where whole tiles need > 200.
+// One piece of work: scan steps [st_lo, st_hi) of one row block, walked from the last to the first.  The reverse carry
+// entering at st_hi is zero (cin 0: the end of the sequence), the composition of the segment summaries (cin 1), or handed
+// over by the workgroup that walked the steps above (cin 2: chained walk); cout: this piece hands its carry on.
+struct RlPiece { int b, g, rbg, st_lo, st_hi, cin, cout, seg; };
+
 template <int NS, bool REV>
-__device__ __forceinline__ void scan_bwdr_body(const BwdArgs& q, float* smem, int b, int g, int rbg, int seg) {
+__device__ __forceinline__ void scan_bwdr_body(const BwdArgs& q, float* smem, const RlPiece pc) {
     constexpr int T = kRT, H = kRT / 2;
+    // wave-uniform by construction (block index arithmetic); said explicitly, because integer divisions are expanded on
+    // the vector ALU and would otherwise make every address derived from them look divergent (no scalar loads)
+    const int b = __builtin_amdgcn_readfirstlane(pc.b), g = __builtin_amdgcn_readfirstlane(pc.g);
+    const int rbg = __builtin_amdgcn_readfirstlane(pc.rbg), seg = __builtin_amdgcn_readfirstlane(pc.seg);
     const FwdArgs& p = q.f;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -220,10 +229,24 @@ __device__ __forceinline__ void scan_bwdr_body(const BwdArgs& q, float* smem, in
     const int o_ns_lane = (int)(lane < 32 ? o_nsB : o_nsC);
 
     // scan steps [st_lo, st_hi) of this workgroup, walked from the last to the first
-    const int st_lo = q.S > 1 ? seg * q.seg_tiles : 0;
-    const int st_hi = q.S > 1 ? (st_lo + q.seg_tiles < ntiles ? st_lo + q.seg_tiles : ntiles) : ntiles;
+    const int st_lo = __builtin_amdgcn_readfirstlane(pc.st_lo), st_hi = __builtin_amdgcn_readfirstlane(pc.st_hi);
     const int nst = st_hi - st_lo;
-    if (q.S > 1) {
+    const long rb_carry = (((long)b * p.G + g) * q.P + rbg) * N * 64 + (long)n0 * 64 + lane;   // this lane's slot of the hand-over
+    if (pc.cin == 2) {
+        // chained walk: wait for the workgroup that walked the steps above (one relaxed poll loop in one lane, then an
+        // agent-scope acquire, then the barrier: MI355X_MICROARCH.md, inter-workgroup visibility).  The producer ran this
+        // row block FIRST and this is our LAST piece, so the flag is normally up; the spin is bounded all the same.
+        if (tid == 0) {
+            int* flag = q.chain_flag + ((b * p.G + g) * q.P + rbg);
+            for (int spin = 0; spin < (1 << 22) && __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0; ++spin)
+                __builtin_amdgcn_s_sleep(16);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < NS; ++s) ecar[s] = q.chain_carry[rb_carry + s * 64];
+    }
+    if (pc.cin == 1) {
         // reverse carry entering the right end = composition of the summaries of the segments after this one
         const float2* __restrict__ sm = reinterpret_cast<const float2*>(q.summ);
         for (int t = q.S - 1; t > seg; --t) {
@@ -495,6 +518,18 @@ __device__ __forceinline__ void scan_bwdr_body(const BwdArgs& q, float* smem, in
     for (int it = it0; it < it1; ++it) step(it, std::false_type{});
     if (it1 < nst) step(it1, std::true_type{});
     RLPROF_FLUSH(g_bwdr_prof)
+    if (pc.cout) {
+        // hand the reverse carry to the workgroup that walks the steps below: plain stores, barrier, one lane releases
+        // at agent scope, drains its stores (the compiler may drop the wait: asm) and raises the flag
+#pragma unroll
+        for (int s = 0; s < NS; ++s) q.chain_carry[rb_carry + s * 64] = ecar[s];
+        __syncthreads();
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(q.chain_flag + ((b * p.G + g) * q.P + rbg), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     if (touch_acc == 1.2345678e-30f) du_blk[0] = touch_acc;        // keeps the touches alive (never true in practice)
 
     // per-row results: one atomicAdd per (row, state) / row and workgroup (several workgroups only with segments)
@@ -605,35 +640,80 @@ __device__ __forceinline__ void scan_bwdr_summary_body(const BwdArgs& q, float* 
         sm[(((long)(seg - 1) * p.batch * (p.dim >> 6) + rowblock) * N + n0 + s) * 64 + lane] = make_float2(fast_exp2(Pacc[s]), ecar[s]);
 }
 
-// MODE 0: the backward proper; MODE 1: the summaries of segments 1 .. S-1
+// MODE 0: the backward proper; MODE 1: the summaries of segments 1 .. S-1; MODE 2: the backward as a chained walk
 template <int NS, int MODE>
 __global__ void __launch_bounds__(256, MODE == 1 ? 4 : 3)
 scan_bwdr_kernel(const BwdArgs q) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int ntiles = (q.f.L + kRT - 1) / kRT;
+    if (MODE == 2) {
+        // Row blocks laid end to end, each walked from its last scan step to its first: position p = row block *
+        // ntiles + (ntiles - 1 - step).  This workgroup owns [p0, p1).  A row block cut at p1 is STARTED here (no
+        // incoming carry) and finished by the next workgroup: it is walked first, so that its carry is ready long
+        // before the neighbour -- which walks its own cut-off head last -- asks for it.
+        // (host: row blocks x tiles < 2^31.  Divisions are expanded on the vector ALU: the results are declared uniform,
+        // or the whole piece loop would count as divergent control flow and lose its scalar loads.)
+        const int W = q.chain_W, total = q.f.batch * q.f.G * q.P * ntiles;
+        const int p0 = (int)blockIdx.x * W, p1 = p0 + W < total ? p0 + W : total;
+        if (p0 >= p1) return;
+        const int r_first = __builtin_amdgcn_readfirstlane(p0 / ntiles), o_first = p0 - r_first * ntiles;
+        const int r_last = __builtin_amdgcn_readfirstlane((p1 - 1) / ntiles), o_end = p1 - r_last * ntiles;   // offsets [.., o_end) of r_last
+        auto run = [&](int r, int oa, int ob) {                                                 // offsets [oa, ob) of row block r
+            RlPiece pc;
+            const int bg = __builtin_amdgcn_readfirstlane(r / q.P);
+            pc.rbg = r - bg * q.P;
+            pc.b = __builtin_amdgcn_readfirstlane(bg / q.f.G);
+            pc.g = bg - pc.b * q.f.G;
+            pc.st_hi = ntiles - oa; pc.st_lo = ntiles - ob;
+            pc.cin = oa > 0 ? 2 : 0; pc.cout = ob < ntiles ? 1 : 0; pc.seg = 0;
+            if ((q.f.rev_mask >> pc.g) & 1u) scan_bwdr_body<NS, true>(q, smem, pc);
+            else scan_bwdr_body<NS, false>(q, smem, pc);
+            __syncthreads();                                        // the next piece reuses the LDS
+        };
+        const int head = o_first > 0 ? 1 : 0;                       // r_first continues a walk begun by the previous workgroup
+        const int tail = (o_end < ntiles && (r_last != r_first || !head)) ? 1 : 0;
+        const int nwhole = (r_last - tail) - (r_first + head) + 1;  // whole row blocks in between (may be <= 0)
+        const int npieces = tail + (nwhole > 0 ? nwhole : 0) + head;
+        for (int i = 0; i < npieces; ++i) {                         // ONE call site: the cut-off tail first, the head last
+            int r, oa = 0, ob = ntiles;
+            if (tail && i == 0) { r = r_last; ob = o_end; }
+            else if (head && i == npieces - 1) { r = r_first; oa = o_first; ob = r_last == r_first ? o_end : ntiles; }
+            else r = r_first + head + (i - tail);
+            run(r, oa, ob);
+        }
+        return;
+    }
     const int lb = xcd_logical_block(blockIdx.x, gridDim.x);
     const int S = MODE == 1 ? q.S - 1 : q.S;
     const int PS = q.P * S;                                   // workgroups per (batch, group): row blocks x segments
     const int per_b = q.f.G * PS;
-    const int b = lb / per_b;
+    const int b = __builtin_amdgcn_readfirstlane(lb / per_b);
     const int rem = lb - b * per_b;
-    const int g = rem / PS;
+    const int g = __builtin_amdgcn_readfirstlane(rem / PS);
     const int rem2 = rem - g * PS;
-    const int rbg = rem2 / S;
+    const int rbg = __builtin_amdgcn_readfirstlane(rem2 / S);
     const int seg = rem2 - rbg * S + (MODE == 1 ? 1 : 0);
     const bool rev = (q.f.rev_mask >> g) & 1u;
     if (MODE == 1) {
         if (rev) scan_bwdr_summary_body<NS, true>(q, smem, b, g, rbg, seg);
         else scan_bwdr_summary_body<NS, false>(q, smem, b, g, rbg, seg);
     } else {
-        if (rev) scan_bwdr_body<NS, true>(q, smem, b, g, rbg, seg);
-        else scan_bwdr_body<NS, false>(q, smem, b, g, rbg, seg);
+        RlPiece pc;
+        pc.b = b; pc.g = g; pc.rbg = rbg; pc.seg = seg;
+        pc.st_lo = q.S > 1 ? seg * q.seg_tiles : 0;
+        pc.st_hi = q.S > 1 ? (pc.st_lo + q.seg_tiles < ntiles ? pc.st_lo + q.seg_tiles : ntiles) : ntiles;
+        pc.cin = q.S > 1 ? 1 : 0; pc.cout = 0;
+        if (rev) scan_bwdr_body<NS, true>(q, smem, pc);
+        else scan_bwdr_body<NS, false>(q, smem, pc);
     }
 }
 
 template <int NS, int MODE>
 static hipError_t launch_bwdr_t(const BwdArgs& a, hipStream_t stream) {
     const int S = MODE == 1 ? a.S - 1 : a.S;
-    const int grid = a.f.batch * a.f.G * a.P * S;
+    const int ntiles = (a.f.L + kRT - 1) / kRT;
+    const long nrb = (long)a.f.batch * a.f.G * a.P;
+    const int grid = MODE == 2 ? (int)((nrb * ntiles + a.chain_W - 1) / a.chain_W) : (int)(nrb * S);
     const size_t lds = bwdr_lds_bytes(4);
     auto kern = scan_bwdr_kernel<NS, MODE>;
     static std::atomic<size_t> lds_cap[kMaxDevices];
@@ -644,6 +724,10 @@ static hipError_t launch_bwdr_t(const BwdArgs& a, hipStream_t stream) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
         lds_cap[dev].store(lds, std::memory_order_relaxed);
+    }
+    if (MODE == 2) {
+        hipError_t e = hipMemsetAsync(a.chain_flag, 0, (size_t)nrb * sizeof(int), stream);
+        if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, stream, a);
     return hipGetLastError();
@@ -659,13 +743,40 @@ static hipError_t launch_bwdr_ns(const BwdArgs& a, hipStream_t stream) {
     }
 }
 
-// a.P = 64-row blocks per (batch, group); a.S segments of a.seg_tiles tiles (a.summ when S > 1)
+// workgroups of the backward proper one CU holds (registers, LDS): the chained walk needs every workgroup resident
+int bwdr_resident_per_cu(int N) {
+    static std::atomic<int> cache[kMaxDevices][3];
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (dev < 0 || dev >= kMaxDevices) dev = 0;
+    const int slot = N == 16 ? 0 : N == 8 ? 1 : 2;
+    int v = cache[dev][slot].load(std::memory_order_relaxed);
+    if (v > 0) return v;
+    const size_t lds = bwdr_lds_bytes(4);
+    int n = 0;
+    hipError_t e = hipSuccess;
+    auto probe = [&](auto kern) {
+        if (lds > 48 * 1024) e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, 256, lds);
+    };
+    if (N == 16) probe(scan_bwdr_kernel<4, 2>); else if (N == 8) probe(scan_bwdr_kernel<2, 2>); else probe(scan_bwdr_kernel<1, 2>);
+    if (e != hipSuccess || n < 1) n = 1;
+    cache[dev][slot].store(n, std::memory_order_relaxed);
+    return n;
+}
+
+// a.P = 64-row blocks per (batch, group); a.S segments of a.seg_tiles tiles (a.summ when S > 1); a.chain_W > 0: chained walk
 hipError_t launch_scan_bwdr(const BwdArgs& a, hipStream_t stream) {
-    if (a.S > 1) {
-        hipError_t e = launch_bwdr_ns<1>(a, stream);
-        if (e != hipSuccess) return e;
+    hipError_t e;
+    if (a.chain_W > 0) {
+        e = launch_bwdr_ns<2>(a, stream);
+    } else {
+        if (a.S > 1) {
+            e = launch_bwdr_ns<1>(a, stream);
+            if (e != hipSuccess) return e;
+        }
+        e = launch_bwdr_ns<0>(a, stream);
     }
-    hipError_t e = launch_bwdr_ns<0>(a, stream);
     if (e != hipSuccess || a.P == 1) return e;
     return launch_reduce_partials(a, stream);
 }

@@ -519,6 +519,12 @@ struct BwdArgs {
     int S;                          // scan_bwd4: sequence segments (1 = whole sequence per workgroup)
     int seg_tiles;                  // scan_bwd4: 160-tiles per segment
     float* summ;                    // scan_bwd4, S > 1: [(S-1)][batch][dim][N][2] reverse summaries (decay product, e) of segments 1..S-1
+    // row-lane backward, chained walk (scan_bwdr.hip): workgroup w owns the tiles [w * chain_W, (w + 1) * chain_W) of the
+    // row blocks laid end to end; a row block cut between two workgroups hands its reverse carry over through
+    // chain_carry [row blocks][N][64] behind chain_flag [row blocks] (zeroed by the launcher); 0 = one piece per workgroup
+    int chain_W;
+    float* chain_carry;
+    int* chain_flag;
     long g_bs, g_ds, du_bs, du_ds, dd_bs, dd_ds, dA_ds, dA_ns;
     long dB_bs, dB_gs, dB_ns, dC_bs, dC_gs, dC_ns;
 };

@@ -63,7 +63,8 @@ hipError_t launch_scan_bwd3(const BwdArgs& a, int dtype, bool glds, hipStream_t 
 hipError_t launch_scan_fwd4(const FwdArgs& a, hipStream_t stream);   // a.R = waves (4 rows each), a.rowblocks = workgroups per (batch, group)
 hipError_t launch_scan_bwd4(const BwdArgs& a, hipStream_t stream);   // a.f.R = waves (4 rows each), a.slab2 = states per barrier
 hipError_t launch_scan_fwdr(const FwdArgs& a, hipStream_t stream);   // a.rowblocks = 64-row blocks per (batch, group); a.segs / a.seg_tiles / a.fsumm
-hipError_t launch_scan_bwdr(const BwdArgs& a, hipStream_t stream);   // a.P = 64-row blocks per (batch, group); a.S / a.seg_tiles / a.summ
+hipError_t launch_scan_bwdr(const BwdArgs& a, hipStream_t stream);
+int bwdr_resident_per_cu(int N);                                     // workgroups of scan_bwdr_kernel a CU holds (occupancy query, cached)   // a.P = 64-row blocks per (batch, group); a.S / a.seg_tiles / a.summ
 hipError_t launch_reduce_partials(const BwdArgs& a, hipStream_t stream);
 hipError_t bwd4_prof_read(unsigned long long* out16);
 hipError_t fwdr_prof_read(unsigned long long* out16);     // development builds (SIGMA_RL_PROF), zeros otherwise

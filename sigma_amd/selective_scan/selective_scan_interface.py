@@ -49,7 +49,8 @@ class SelectiveScanFn(torch.autograd.Function):
         # (include/sigma_scan.h, ckpt_pitch): the backward then runs csrc/scan_bwd2.hip.  The module-level
         # ``selective_scan_cuda_core.fwd`` keeps the reference-shaped x (selective_scan.cpp:225-228).
         ctx.pitch = ckpt_pitch_for(u.shape[-1], A.shape[1], delta.shape[0] * delta.shape[1],
-                                   _core.quad_backward_ok(u, delta, B, C) and nrows == 1)
+                                   _core.quad_backward_ok(u, delta, B, C) and nrows == 1,
+                                   _core.rowlane_ok(u, delta, B, C), B.shape[1])
         out, x = _core.fwd_ext(u, delta, A, B, C, D, delta_bias, delta_softplus, nrows=nrows, ckpt_pitch=ctx.pitch)
         ctx.delta_softplus = delta_softplus
         ctx.save_for_backward(u, delta, A, B, C, D, delta_bias, x)
@@ -59,6 +60,8 @@ class SelectiveScanFn(torch.autograd.Function):
     def backward(ctx, dout, *unused):
         u, delta, A, B, C, D, delta_bias, x = ctx.saved_tensors
         dout = _last_contig(dout)
+        if ctx.pitch == 16 and not _core.rowlane_ok(u, delta, B, C, dout):
+            dout = dout.contiguous().clone() if dout.data_ptr() % 16 else dout.contiguous()   # the row-lane backward wants aligned rows
         du, ddelta, dA, dB, dC, dD, ddelta_bias = _core.bwd_ext(
             u, delta, A, B, C, D, delta_bias, dout, x, ctx.delta_softplus, nrows=1, ckpt_pitch=ctx.pitch)
         if ctx.squeeze_B:

@@ -49,9 +49,31 @@ import os as _os
 _CKPT_ENV = _os.environ.get("SIGMA_CKPT_PITCH", "auto")
 
 
-def ckpt_pitch_for(seqlen: int, dstate: int = 16, rows: int = 0, quad_ok: bool = False, rowlane_ok: bool = False) -> int:
+def rowlane_pays(seqlen: int, dstate: int, rows: int, groups: int) -> bool:
+    """Launch shapes on which the row-lane kernels (csrc/scan_fwdr.hip / scan_bwdr.hip, checkpoint pitch 16) beat the
+    quad-row / 64-lane kernels in forward + backward time, from the shape-by-shape comparison on MI355X
+    (profiles/r04_rowlane_vs_auto.txt; tools/gpu_r4.sh e):
+      * 16 (8) states: sequences of ~1200 at any batch (the dominant launch of the training step, (16,3072,1200): 1133
+        against 1339 us), and every launch with few rows (one image per GPU: (2,768,19200) 930 / 985, (2,1536,4800)
+        472 / 508, (2,3072,1200) 253 / 292) -- not L = 300 (its 19 tiles do not amortise the workgroup set-up) and not
+        the long sequences at batch 16 ((16,768,19200): 5915 / 5083: twelve row blocks per CU-load of sequential tiles);
+      * 4 states (fusion blocks, decoder): launches with few rows -- everything the one-image step runs except L = 300
+        ((1,192,19200) 146 / 450 us, (1,384,38400) 305 / 900, (1,768,19200) 259 / 498), and the single-group CroMB
+        launches of the batch-8 step; with many rows the 4-state scans are bound by memory traffic, where the 64-lane
+        forward is ahead."""
+    if seqlen < 600:
+        return False
+    if dstate >= 8:
+        return (600 <= seqlen <= 2400) or rows <= 8192
+    return (rows <= 3072 and rows * seqlen <= 32_000_000) or (groups == 1 and rows <= 8192 and seqlen <= 2400)
+
+
+def ckpt_pitch_for(seqlen: int, dstate: int = 16, rows: int = 0, quad_ok: bool = False, rowlane_ok: bool = False,
+                   groups: int = 0) -> int:
     """Checkpoint pitch = backward tile length (include/sigma_scan.h).  Measured on MI355X
-    (profiles/r02_bwd_plans.txt, profiles/r02_bwd4_shapes.txt):
+    (profiles/r02_bwd_plans.txt, profiles/r02_bwd4_shapes.txt, profiles/r04_rowlane_vs_auto.txt):
+      * 16 (row-lane kernels, csrc/scan_fwdr.hip / scan_bwdr.hip; ``rowlane_ok`` = selective_scan_cuda_core.rowlane_ok
+        of the operands) on the launch shapes ``rowlane_pays`` lists;
       * 160 (quad-row backward, csrc/scan_bwd4.hip; ``quad_ok`` = selective_scan_cuda_core.quad_backward_ok of the
         operands) whenever there are enough rows for workgroups of 8+ waves on every CU (batch * dim >= 8192 with
         8+ states; >= 12288 with 4 states up to 4800 elements, where the per-tile overhead weighs more) -- 8-27 %
@@ -62,10 +84,12 @@ def ckpt_pitch_for(seqlen: int, dstate: int = 16, rows: int = 0, quad_ok: bool =
         elements (state-parallel backward, csrc/scan_bwd3.hip) and for 16-state scans up to 4800 elements with
         enough rows for the row-block loop of csrc/scan_bwd2.hip;
       * 640 otherwise."""
-    if _CKPT_ENV != "auto":
+    if _CKPT_ENV not in ("auto", "norowlane"):
         forced = int(_CKPT_ENV)
         if (forced != 160 or quad_ok) and (forced != 16 or rowlane_ok):
             return forced
+    if rowlane_ok and _CKPT_ENV != "norowlane" and rowlane_pays(seqlen, dstate, rows, groups):
+        return 16
     if quad_ok and ((dstate >= 8 and rows >= 8192) or (rows >= 12288 and seqlen <= 4800)):
         return 160
     if quad_ok and dstate >= 8 and seqlen >= 4800:
@@ -220,7 +244,8 @@ class SelectiveScanExtFn(torch.autograd.Function):
         B = B.float() if B.stride(-1) == 1 else B.float().contiguous()
         C = C.float() if C.stride(-1) == 1 else C.float().contiguous()
         A, D, delta_bias = A.float().contiguous(), D.float().contiguous(), delta_bias.float().contiguous()
-        pitch = ckpt_pitch_for(u.shape[-1], A.shape[1], delta.shape[0] * delta.shape[1], _core.quad_backward_ok(u, delta, B, C))
+        pitch = ckpt_pitch_for(u.shape[-1], A.shape[1], delta.shape[0] * delta.shape[1], _core.quad_backward_ok(u, delta, B, C),
+                               _core.rowlane_ok(u, delta, B, C), B.shape[1])
         out, ck = _core.fwd_ext(u, delta, A, B, C, D, delta_bias, True, rev_mask=rev_mask, u_gshift=u_gshift,
                                 need_x=any(ctx.needs_input_grad), ckpt_pitch=pitch)
         ctx.save_for_backward(u, delta, A, B, C, D, delta_bias, ck)
@@ -332,7 +357,7 @@ class SS2DCoreFn(torch.autograd.Function):
         Bv, Cv = p4[:, :, R:R + N], p4[:, :, R + N:]
         need_x = any(ctx.needs_input_grad)
         u2, dl2 = xs2.view(B, 2 * d, L), delta.view(B, 4 * d, L)
-        pitch = ckpt_pitch_for(L, N, B * 4 * d, _core.quad_backward_ok(u2, dl2, Bv, Cv))
+        pitch = ckpt_pitch_for(L, N, B * 4 * d, _core.quad_backward_ok(u2, dl2, Bv, Cv), _core.rowlane_ok(u2, dl2, Bv, Cv), 4)
         out, ck = _core.fwd_ext(u2, dl2, A, Bv, Cv, Dp, bias, True, rev_mask=_REV_MASK, u_gshift=1, need_x=need_x,
                                 ckpt_pitch=pitch, param_swap=1)
         ctx.pitch = pitch

@@ -99,3 +99,64 @@ def test_dominant_launch_plans_are_the_documented_ones():
     assert rc == 0 and b[:3] == [10, 12, 256] and b[4] == -1
     rc, f = _plan(lib.sigma_scan_fwd_plan, _params(16, 3072, 1200, 16, 4, 160))
     assert rc == 0 and f[0] == 10 and f[1] == 8 and f[5] == -100
+
+
+def test_row_lane_plans_of_every_model_shape():
+    """ckpt_pitch 16 (csrc/scan_fwdr.hip / scan_bwdr.hip): every model shape with rows per group divisible by 64 gets a
+    legal plan -- state waves dividing dstate, segments of >= 2 tiles none of them empty, workspace = slabs + summaries +
+    the hand-over slots of the chained walk -- and the others are refused by BOTH entry points."""
+    lib = _capi.load()
+    seen = 0
+    for (dim, N, G), L, batch in itertools.product(MODEL_DIMS, LENGTHS, BATCHES):
+        bp = _params(batch, dim, L, N, G, 16)
+        rpg = dim // G
+        rc, f = _plan(lib.sigma_scan_fwd_plan, bp)
+        rcb, b = _plan(lib.sigma_scan_bwd_plan, bp)
+        if rpg % 64 != 0:
+            assert rc != 0 and rcb != 0 and "16" in _capi.last_error()
+            assert lib.sigma_scan_bwd_workspace_bytes(ctypes.byref(bp)) < 0
+            continue
+        assert rc == 0 and rcb == 0, (_capi.last_error(), dim, L, batch)
+        ntiles = (L + 15) // 16
+        P = rpg // 64
+        for plan, backward in ((f, False), (b, True)):
+            items, nw, grid, lds, S, tag = plan
+            assert items == 16 and tag == -200 and 0 < lds <= LDS_LIMIT // 2
+            assert nw in (4, 8, 16) and N % nw == 0 and (not backward or nw == 4)
+            assert 1 <= S <= 64 and grid == batch * G * P * S
+            st = (ntiles + S - 1) // S
+            assert S == 1 or (st >= 2 and st * (S - 1) < ntiles)
+            summ = (S - 1) * batch * dim * N * 2 * 4
+            if backward:
+                nrb = batch * dim // 64
+                chain = (nrb * N * 64 + (nrb + 3) // 4 * 4) * 4
+                slabs = 0 if P == 1 else 2 * P * batch * G * N * L * 4
+                assert lib.sigma_scan_bwd_workspace_bytes(ctypes.byref(bp)) == slabs + summ + chain
+            else:
+                assert lib.sigma_scan_fwd_workspace_bytes(ctypes.byref(bp.fwd)) == summ
+        seen += 1
+    assert seen > 300
+
+
+def test_row_lane_policy_matches_the_measured_table():
+    """ss2d_fused.rowlane_pays against profiles/r04_rowlane_vs_auto.txt (forward + backward time of the row-lane kernels
+    against the round-3 planner's kernels on MI355X): the policy picks the faster side on every launch shape of the
+    batch-8 and the one-image training step, except where the two are within 5 %."""
+    import json
+    import os
+    from sigma_amd.ss2d_fused import ckpt_pitch_for, rowlane_pays
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles")
+    a = {json.loads(l)["shape"]: json.loads(l) for l in open(os.path.join(root, "r04_rowlane_p16_scan_bench.jsonl"))}
+    b = {json.loads(l)["shape"]: json.loads(l) for l in open(os.path.join(root, "r04_rowlane_auto_scan_bench.jsonl"))}
+    assert len(a) >= 30
+    for k in a:
+        B, KD, L, N, G = a[k]["dims"]
+        ta, tb = a[k]["fwd_us"] + a[k]["bwd_us"], b[k]["fwd_us"] + b[k]["bwd_us"]
+        if abs(ta - tb) <= 0.05 * tb:
+            continue
+        assert rowlane_pays(L, N, B * KD, G) == (ta < tb), (k, ta, tb)
+    # the dominant launch of the benchmark step and SURVEY's headline shape go to the row-lane kernels, when they can take them
+    assert ckpt_pitch_for(1200, 16, 16 * 3072, True, True, 4) == 16
+    assert ckpt_pitch_for(19200, 16, 768, True, True, 4) == 16
+    assert ckpt_pitch_for(1200, 16, 16 * 3072, True, False, 4) == 160
+    assert ckpt_pitch_for(19200, 16, 16 * 768, True, True, 4) == 160

@@ -577,3 +577,136 @@ def test_full_size_properties_linearity_and_determinism():
     torch.testing.assert_close(lhs, rhs, rtol=2e-4, atol=2e-4)
     # determinism of the forward (no atomics on the forward path)
     assert torch.equal(f(u), f(u))
+
+
+# ---- row-lane kernels (csrc/scan_fwdr.hip / scan_bwdr.hip, checkpoint pitch 16; round 4) ------------------------------
+ROWLANE_CASES = [
+    # (batch, KD, L, N, G, rev_mask, u_gshift), library options
+    ((2, 256, 1200, 16, 4, 0b1010, 1), {}),                  # one row block per group: dB/dC written directly
+    ((2, 512, 1200, 16, 4, 0b1010, 1), {}),                  # two row blocks per group: workspace slabs + reduce
+    ((1, 256, 1204, 16, 4, 0b0110, 1), {}),                  # partial last tile (L % 16 == 4), other flip pattern
+    ((3, 192, 300, 8, 1, 0, 0), {}),                         # 8 states, one group, L % 16 == 12
+    ((3, 192, 300, 8, 1, 1, 0), {"rl_waves": 8}),            # 8 states, eight forward state waves, reversed
+    ((2, 384, 2564, 4, 2, 0b10, 1), {}),                     # 4 states (fusion / decoder), ConMB's flipped second group
+    ((2, 256, 1200, 16, 4, 0b1010, 1), {"rl_segs": 3}),      # forced sequence segments (summary pre-passes)
+    ((2, 256, 1200, 16, 4, 0b1010, 1), {"rl_segs": 5, "rl_waves": 8}),
+    ((2, 256, 1200, 16, 4, 0b1010, 1), {"rl_waves": 16}),    # forward with 16 state waves
+    ((1, 256, 4800, 16, 4, 0b1010, 1), {}),                  # few rows: automatic segments
+    ((1, 768, 19200, 16, 4, 0b1010, 1), {}),                 # one image per GPU, encoder stage 0 (SURVEY's headline shape)
+    ((1, 384, 38400, 4, 2, 0b10, 1), {}),                    # one image per GPU, ConMB stage 0 (the longest sequence at 480x640)
+    ((11, 3072, 176, 16, 4, 0b1010, 1), {"rl_chain": 2}),    # 528 row blocks > resident workgroups: chained walk of the backward
+    ((11, 3072, 172, 16, 4, 0b0101, 1), {"rl_chain": 2}),    # ... with a partial last tile
+    ((2, 64, 16, 4, 1, 0, 0), {}),                           # exactly one tile
+    ((2, 64, 8, 4, 1, 1, 0), {}),                            # less than one tile, reversed
+]
+
+
+def _rowlane_id(c):
+    shape, opts = c
+    return "x".join(map(str, shape[:5])) + (("-" + ",".join(f"{k}={v}" for k, v in opts.items())) if opts else "")
+
+
+def _rowlane_run(shape, opts, softplus=True, with_D=True, with_bias=True, seed=23):
+    batch, KD, L, N, G, mask, ush = shape
+    u, delta, A, B, C, D, bias, dout = _model_like(batch, KD, L, N, G, seed=seed)
+    if not softplus:
+        delta, bias = delta.abs(), bias.abs()             # a negative step size makes the recurrence itself explode
+    if not with_D:
+        D = None
+    if not with_bias:
+        bias = None
+    rpg = KD // G
+    keep = lambda t: torch.cat([t[:, g * rpg:(g + 1) * rpg] for g in range(0, G, 1 << ush)], dim=1).contiguous()
+    full = lambda t: torch.cat([t[:, (g >> ush) * rpg:((g >> ush) + 1) * rpg] for g in range(G)], dim=1)
+    u_h, g_h = keep(u), keep(dout)
+    u_f, g_f = full(u_h), full(g_h)
+    core = _core()
+    dev = "cuda"
+    args = [None if t is None else t.to(dev) for t in (u_h, delta, A, B, C, D, bias)]
+    assert core.rowlane_ok(args[0], args[1], args[3], args[4])
+    from sigma_amd import _capi
+    try:
+        for k, v in opts.items():
+            _capi.set_option(k, v)
+        out, x = core.fwd_ext(*args, softplus, rev_mask=mask, u_gshift=ush, ckpt_pitch=16)
+        out_nox, _ = core.fwd_ext(*args, softplus, rev_mask=mask, u_gshift=ush, ckpt_pitch=16, need_x=False)
+        grads = core.bwd_ext(*args, g_h.to(dev), x, softplus, rev_mask=mask, u_gshift=ush, dout_gshift=ush, ckpt_pitch=16)
+    finally:
+        for k in opts:
+            _capi.set_option(k, 0)
+    assert x.shape == (batch, KD, 2 * max((L + 15) // 16, 1) * N)
+    revs = [(mask >> g) & 1 for g in range(G)]
+    fr = lambda t: torch.cat([t[:, g * rpg:(g + 1) * rpg].flip(-1) if revs[g] else t[:, g * rpg:(g + 1) * rpg] for g in range(G)], 1)
+    fg = lambda t: torch.stack([t[:, g].flip(-1) if revs[g] else t[:, g] for g in range(G)], 1)
+    so = _oracle()
+    ref = fr(so.selective_scan_oracle(fr(u_f), fr(delta), A, fg(B), fg(C), D, bias, softplus, acc64=True))
+    torch.testing.assert_close(out.cpu(), ref, rtol=6e-4, atol=2e-3)
+    assert torch.equal(out_nox, out)                      # inference (no checkpoints) runs the same arithmetic
+    rg = list(so.selective_scan_oracle_bwd(fr(u_f), fr(delta), A, fg(B), fg(C), D, bias, fr(g_f), softplus))
+    rg[0], rg[1], rg[3], rg[4] = fr(rg[0]), fr(rg[1]), fg(rg[3]), fg(rg[4])
+    for name, g, r in zip(["u", "delta", "A", "B", "C", "D", "bias"], grads, rg):
+        if r is None:
+            assert g is None
+            continue
+        torch.testing.assert_close(g.cpu(), r, rtol=3e-3, atol=2e-3 + 2e-4 * float(r.abs().max()),
+                                   msg=lambda m, name=name: f"d{name}: {m}")
+
+
+@pytest.mark.parametrize("case", ROWLANE_CASES, ids=[_rowlane_id(c) for c in ROWLANE_CASES])
+def test_row_lane_kernels_against_oracle(case):
+    """csrc/scan_fwdr.hip / scan_bwdr.hip (ckpt_pitch 16: a lane is a channel row, B / C as scalar operands, per-tile
+    checkpoints, lane-reduce network for dB / dC) against the CPU oracle: forward with and without checkpoints and all
+    seven gradients; reversed groups, shared u / dout rows, partial tiles, workspace slabs, state-wave counts, sequence
+    segments (forced and automatic) and the chained walk."""
+    shape, opts = case
+    _rowlane_run(shape, opts)
+
+
+@pytest.mark.parametrize("flags", [dict(softplus=False), dict(with_D=False, with_bias=False), dict(softplus=False, with_D=False)],
+                         ids=["no-softplus", "no-D-no-bias", "no-softplus-no-D"])
+def test_row_lane_kernels_optional_operands(flags):
+    _rowlane_run((2, 256, 1200, 16, 4, 0b1010, 1), {}, **flags)
+
+
+def test_row_lane_kernels_refuse_what_they_cannot_take():
+    """ckpt_pitch 16 with 16-bit IO, rows per group not divisible by 64 or an odd length must fail loudly in BOTH entry
+    points (no silent fallback), and rowlane_ok says so first."""
+    core = _core()
+    u, delta, A, B, C, D, bias, dout = _model_like(2, 96, 640, 16, 2, seed=5)       # 48 rows per group
+    args = [t.cuda() for t in (u, delta, A, B, C, D, bias)]
+    assert not core.rowlane_ok(args[0], args[1], args[3], args[4])
+    with pytest.raises(RuntimeError):
+        core.fwd_ext(*args, True, ckpt_pitch=16)
+    u, delta, A, B, C, D, bias, dout = _model_like(2, 128, 642, 16, 2, seed=5)      # L % 4 != 0
+    args = [t.cuda() for t in (u, delta, A, B, C, D, bias)]
+    assert not core.rowlane_ok(args[0], args[1], args[3], args[4])
+    with pytest.raises(RuntimeError):
+        core.fwd_ext(*args, True, ckpt_pitch=16)
+    u, delta, A, B, C, D, bias, dout = _model_like(2, 128, 640, 16, 2, seed=5, itype=torch.bfloat16)
+    args = [t.cuda() for t in (u, delta, A, B, C, D, bias)]
+    assert not core.rowlane_ok(args[0], args[1], args[3], args[4])
+    with pytest.raises(RuntimeError):
+        core.fwd_ext(*args, True, ckpt_pitch=16)
+
+
+def test_row_lane_policy_through_the_autograd_function():
+    """selective_scan_fn picks the row-lane kernels by itself on the shapes ckpt_pitch_for lists (here: the one-image
+    ConMB launch) and gives the oracle's gradients through autograd, including an unaligned dout."""
+    from sigma_amd.ss2d_fused import ckpt_pitch_for
+    batch, KD, L, N, G = 1, 384, 2400, 4, 2
+    u, delta, A, B, C, D, bias, dout = _model_like(batch, KD, L, N, G, seed=41)
+    core = _core()
+    dev = "cuda"
+    leaves = [t.to(dev).requires_grad_() for t in (u, delta, A, B, C, D, bias)]
+    assert ckpt_pitch_for(L, N, batch * KD, False, core.rowlane_ok(*[leaves[i].detach() for i in (0, 1, 3, 4)]), G) == 16
+    out = _fn()(*leaves, True, 1)
+    pad = torch.zeros(batch, KD, L + 1, device=dev)
+    pad[..., 1:] = dout.to(dev)
+    out.backward(pad[..., 1:])                             # rows that start 4 bytes off a 16-byte boundary
+    so = _oracle()
+    ref = so.selective_scan_oracle(u, delta, A, B, C, D, bias, True, acc64=True)
+    torch.testing.assert_close(out.detach().cpu(), ref, rtol=6e-4, atol=2e-3)
+    rg = so.selective_scan_oracle_bwd(u, delta, A, B, C, D, bias, dout, True)
+    for name, t, r in zip(["u", "delta", "A", "B", "C", "D", "bias"], leaves, rg):
+        torch.testing.assert_close(t.grad.cpu(), r, rtol=3e-3, atol=2e-3 + 2e-4 * float(r.abs().max()),
+                                   msg=lambda m, name=name: f"d{name}: {m}")

@@ -8,9 +8,15 @@ export TMPDIR=/tmp
 case $step in
 a)  # first light of the row-lane kernels: correctness sweep + timing against the quad-row kernels
     timeout 900 python tools/rowlane_check.py --out $out/rowlane_check.jsonl > $out/rowlane_check.log 2>&1
-    tail -3 $out/rowlane_check.log
+    grep -v "^{" $out/rowlane_check.log | tail -5; python - <<PY
+import json
+for l in open("$out/rowlane_check.jsonl"):
+    r = json.loads(l)
+    bad = {k: (v["bad"], v["nan"], round(v["max_abs"], 6)) for k, v in r.items() if isinstance(v, dict) and "bad" in v and (v["bad"] or v["nan"])}
+    print("ok  " if r["ok"] else "FAIL", r["shape"], r["opts"], r.get("error", ""), bad)
+PY
     for pitch in 16 160; do
-      timeout 600 python tools/scan_bench.py --fine --pitch $pitch --iters 10 --shapes enc_s2_b16,enc_s1_b16,enc_s0_b16,enc_s2_b2,enc_s0 --out $out/scan_bench_p$pitch.jsonl > $out/scan_bench_p$pitch.log 2>&1
+      timeout 600 python tools/scan_bench.py --fine --pitch $pitch --iters 10 --shapes enc_s2_b16,enc_s2_b2,enc_s0 --out $out/scan_bench_p$pitch.jsonl > $out/scan_bench_p$pitch.log 2>&1
       cat $out/scan_bench_p$pitch.log | python -c "
 import sys, json
 for l in sys.stdin:
@@ -42,5 +48,26 @@ d)  # PMC passes of the row-lane kernels (base build and the all-ablated build)
     bash tools/gpu_pmc.sh r4_d/base enc_s2_b16 all > $out/pmc_base.txt 2>&1
     SIGMA_HIP_LIB=$PWD/sigma_amd/lib/libsigma_hip_abl63.so bash tools/gpu_pmc.sh r4_d/abl63 enc_s2_b16 all > $out/pmc_abl63.txt 2>&1
     grep -A3 "^== " $out/pmc_base.txt | grep -v "^--" ; echo ABL63; grep -A3 "^== " $out/pmc_abl63.txt | grep -v "^--"
+    ;;
+e)  # row-lane (pitch 16) against the planner's own choice on every launch shape of the batch-8 and batch-1 steps
+    SH=enc_s0_b16,enc_s1_b16,enc_s2_b16,enc_s3_b16,cromb_s0_b8,cromb_s1_b8,cromb_s2_b8,cromb_s3_b8,conmb_s0_b8,conmb_s1_b8,conmb_s2_b8,conmb_s3_b8,dec_s0_b8,dec_s1_b8,dec_s2_b8,enc_s0_b2,enc_s1_b2,enc_s2_b2,enc_s3_b2,cromb_s0,cromb_s1,cromb_s2,cromb_s3,conmb_s0,conmb_s1,conmb_s2,conmb_s3,dec_s0,dec_s1,dec_s2
+    timeout 900 python tools/scan_bench.py --fine --pitch 16 --iters 10 --shapes $SH --out $out/p16.jsonl > /dev/null 2>&1
+    SIGMA_CKPT_PITCH=auto timeout 900 python tools/scan_bench.py --fine --iters 10 --shapes $SH --out $out/auto.jsonl > /dev/null 2>&1
+    python - <<PY
+import json
+a = {json.loads(l)["shape"]: json.loads(l) for l in open("$out/p16.jsonl")}
+b = {json.loads(l)["shape"]: json.loads(l) for l in open("$out/auto.jsonl")}
+for k in a:
+    x, y = a[k], b[k]
+    print("%-12s %-26s p16 fwd %6.0f bwd %6.0f | pitch %4d fwd %6.0f bwd %6.0f | sum %6.0f vs %6.0f  %s" % (k, x["dims"], x["fwd_us"], x["bwd_us"], y["ckpt_pitch"], y["fwd_us"], y["bwd_us"], x["fwd_us"] + x["bwd_us"], y["fwd_us"] + y["bwd_us"], "ROWLANE" if x["fwd_us"] + x["bwd_us"] < y["fwd_us"] + y["bwd_us"] else ""))
+PY
+    ;;
+f)  # row-lane kernels under pytest + the model with the new pitch policy + bench lines (batch 8, one image per GPU)
+    ( time timeout 900 python -m pytest tests/test_scan_gpu.py -q --tb=short -x -k "row_lane or real_stage or reversed_groups or checkpoint_tensor" ) > $out/pytest_scan.log 2>&1; tail -4 $out/pytest_scan.log | cut -c1-200
+    ( time timeout 900 python -m pytest tests/test_model_gpu.py -q --tb=short -x ) > $out/pytest_model.log 2>&1; tail -4 $out/pytest_model.log | cut -c1-200
+    ( timeout 600 python bench.py --no-cpu-baseline ) > $out/bench_b8.log 2>&1; grep "^{" $out/bench_b8.log | cut -c1-600
+    ( SIGMA_CKPT_PITCH=norowlane timeout 600 python bench.py --no-cpu-baseline ) > $out/bench_b8_norowlane.log 2>&1; grep "^{" $out/bench_b8_norowlane.log | cut -c1-300
+    ( timeout 600 python bench.py --per-gpu-batch 1 --graph --no-cpu-baseline ) > $out/bench_b1_graph.log 2>&1; grep "^{" $out/bench_b1_graph.log | cut -c1-300
+    ( SIGMA_CKPT_PITCH=norowlane timeout 600 python bench.py --per-gpu-batch 1 --graph --no-cpu-baseline ) > $out/bench_b1_graph_norowlane.log 2>&1; grep "^{" $out/bench_b1_graph_norowlane.log | cut -c1-300
     ;;
 esac

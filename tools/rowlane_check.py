@@ -40,6 +40,7 @@ def run_case(shape, opts, softplus=True, with_D=True, with_bias=True, seed=23):
     u, delta, A, B, C, D, bias, dout = model_like(batch, KD, L, N, G, seed=seed)
     if not softplus:
         delta = delta.abs()                     # a negative step size makes the recurrence itself explode
+        bias = bias.abs()
     if not with_D:
         D = None
     if not with_bias:
@@ -107,6 +108,9 @@ CASES = [
     ((2, 256, 1200, 16, 4, 0b1010, 1), {"rl_waves": 4}),     # forward with 4 state waves
     ((1, 256, 4800, 16, 4, 0b1010, 1), {}),                  # few rows: automatic segments
     ((1, 768, 19200, 16, 4, 0b1010, 1), {}),                 # one image per GPU, encoder stage 0
+    ((11, 3072, 176, 16, 4, 0b1010, 1), {"rl_chain": 2}),    # 528 row blocks > 512 resident workgroups: chained walk
+    ((11, 3072, 172, 16, 4, 0b0101, 1), {"rl_chain": 2}),    # chained walk with a partial last tile
+    ((11, 3072, 176, 16, 4, 0b1010, 1), {"rl_chain": 1}),    # the same without the chain
     ((2, 64, 16, 4, 1, 0, 0), {}),                           # one tile
     ((2, 64, 8, 4, 1, 1, 0), {}),                            # less than one tile, reversed
 ]

@@ -47,7 +47,24 @@ SHAPES = {
     "base_s2_b2": (2, 4096, 3600, 16, 4),
     "base_s3_b2": (2, 8192, 900, 16, 4),
     "enc_s0_b2": (2, 768, 19200, 16, 4),
+    "enc_s1_b2": (2, 1536, 4800, 16, 4),
     "enc_s2_b2": (2, 3072, 1200, 16, 4),
+    "enc_s3_b2": (2, 6144, 300, 16, 4),
+    "cromb_s1_b8": (8, 384, 4800, 4, 1),
+    "cromb_s2_b8": (8, 768, 1200, 4, 1),
+    "cromb_s3_b8": (8, 1536, 300, 4, 1),
+    "conmb_s1_b8": (8, 768, 9600, 4, 2),
+    "conmb_s2_b8": (8, 1536, 2400, 4, 2),
+    "conmb_s3_b8": (8, 3072, 600, 4, 2),
+    "dec_s0": (1, 768, 19200, 4, 4),
+    "dec_s1": (1, 1536, 4800, 4, 4),
+    "dec_s2": (1, 3072, 1200, 4, 4),
+    "cromb_s1": (1, 384, 4800, 4, 1),
+    "cromb_s2": (1, 768, 1200, 4, 1),
+    "cromb_s3": (1, 1536, 300, 4, 1),
+    "conmb_s1": (1, 768, 9600, 4, 2),
+    "conmb_s2": (1, 1536, 2400, 4, 2),
+    "conmb_s3": (1, 3072, 600, 4, 2),
 }
 
 HBM_PEAK = 8.0e12
