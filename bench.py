@@ -60,9 +60,6 @@ def parse():
     ap.add_argument("--graph", action="store_true",
                     help="capture the step (fwd + bwd + AdamW) as one HIP graph and time replays (single process); the "
                          "roofline object then comes from a few eager steps run before the capture")
-    ap.add_argument("--split-gemm", action="store_true",
-                    help="nn.Linear GEMMs as split-operand bf16 MFMA GEMMs (sigma_amd/split_linear.py: 4e-6 rms error per GEMM, "
-                         "reported as config.gemm; the default and headline stay fp32 GEMMs)")
     ap.add_argument("--gemm", default="", choices=["", "fp32", "split3"],
                     help="nn.Linear GEMMs: split3 = hand-written split-operand bf16 MFMA kernels (csrc/gemm_split.hip), fp32 = vendor "
                          "fp32 GEMMs; default: sigma_amd.gemm.gemm_mode()")
@@ -210,8 +207,7 @@ def main():
     plan = ts.launch_plan(a.gpus, os.environ, torch.cuda.device_count() if torch.cuda.is_available() else 0,
                           sys.argv[1:], os.path.abspath(__file__), port)
     if plan[0] == "spawn":           # `python bench.py --gpus N`: become N ranks (one per GPU, RCCL)
-        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        raise SystemExit(subprocess.call(plan[1], env=env))
+        raise SystemExit(subprocess.call(plan[1], env=ts.spawn_env(os.environ)))
     _, world, rank, local = plan
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -225,8 +221,6 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
 
-    if a.split_gemm:
-        os.environ["SIGMA_SPLIT_GEMM"] = "1"
     if a.gemm:
         os.environ["SIGMA_GEMM"] = a.gemm
     from sigma_amd import selective_scan_cuda_core as core
@@ -265,7 +259,9 @@ def main():
 
     if use_graph:
         # kernel timings (HIP events per launch) cannot live inside a captured graph: take them from two
-        # eager steps first, then capture and time replays of the identical step
+        # eager steps first, then capture and time replays of the identical step.  (Under a process group these eager
+        # steps run on the unwrapped model, i.e. without the gradient all-reduce: make_graphed_ddp_step re-broadcasts the
+        # parameters and discards the optimizer state afterwards, so the replicas start the timed steps identical.)
         step(); torch.cuda.synchronize()
         timer.enabled = True
         step(); step(); torch.cuda.synchronize()

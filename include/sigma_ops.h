@@ -146,18 +146,6 @@ int sigma_softmax_ce_fwd(const float *logits, const int64_t *labels, int64_t row
 int sigma_softmax_ce_bwd(const float *logits, const int64_t *labels, const float *lse, const float *scale, int64_t rows,
                          int32_t classes, int64_t ignore_index, float *dlogits, void *stream);
 
-/*   sigma_split_bf16
- *       Operand images of the split-operand bf16 GEMM (sigma_amd/split_linear.py; the nn.Linear calls of
- *       vmamba.py, e.g. SS2D.in_proj / out_proj :1067-1089): with hi = bf16(x) and lo = bf16(x - hi), row r of the
- *       fp32 source (rows x cols, row stride src_row_stride elements) is written as bf16 to
- *           dst + r * dst_row_stride              <- hi
- *           dst + r * dst_row_stride + hi2_offset <- hi again (skipped when hi2_offset < 0)
- *           dst + r * dst_row_stride + lo_offset  <- lo
- *       (offsets in bf16 elements), so that [hi | hi | lo], [hi | lo | hi] (concatenation along the columns) and
- *       [hi ; lo ; hi] (along the rows) come out of one pass.                                              */
-int sigma_split_bf16(const float *src, int64_t rows, int64_t cols, int64_t src_row_stride, void *dst, int64_t dst_row_stride,
-                     int64_t hi2_offset, int64_t lo_offset, void *stream);
-
 /*   sigma_layernorm_fwd / sigma_layernorm_bwd
  *       nn.LayerNorm(C, eps=1e-5, affine) over the last dimension of a contiguous (rows, C) fp32
  *       tensor: every LayerNorm of the hot path (vmamba.py:617, 724, 1183-1184, 1448-1449, 1693,

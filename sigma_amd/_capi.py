@@ -141,7 +141,7 @@ GEMM_SYMBOLS = ("sigma_gemm_nt_split3", "sigma_gemm_nn_split3", "sigma_gemm_tn_s
 # every symbol include/sigma_ops.h declares
 OPS_SYMBOLS = ("sigma_dwconv3x3_silu_fwd", "sigma_dwconv3x3_silu_bwd", "sigma_cross_merge_nhwc", "sigma_cross_split_nhwc",
                "sigma_layernorm_fwd", "sigma_layernorm_bwd", "sigma_layernorm_bwd_partial_rows", "sigma_transpose2d",
-               "sigma_pair_sum_add", "sigma_split_bf16", "sigma_upsample2x_nhwc", "sigma_plane_pool", "sigma_plane_scale",
+               "sigma_pair_sum_add", "sigma_upsample2x_nhwc", "sigma_plane_pool", "sigma_plane_scale",
                "sigma_plane_dot", "sigma_plane_gate_bwd", "sigma_softmax_ce_fwd", "sigma_softmax_ce_bwd")
 
 # every symbol include/sigma_scan.h declares; tests check the library exports all of them
@@ -222,9 +222,6 @@ def load() -> ctypes.CDLL:
         elif name == "sigma_softmax_ce_bwd":
             fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32,
                            ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]
-        elif name == "sigma_split_bf16":
-            fn.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
-                           ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]
         else:
             st = (MergeParams if "cross_" in name else LayerNormParams if "layernorm" in name else
                   TransposeParams if "transpose" in name else DwConvParams)

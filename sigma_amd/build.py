@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "lib", "obj")
 LIB = os.path.join(HERE, "lib", "libsigma_hip.so")
-SOURCES = ["scan_fwd.hip", "scan_fwd4.hip", "scan_fwdr.hip", "scan_bwdr.hip", "scan_bwd.hip", "scan_bwd2.hip", "scan_bwd3.hip", "scan_bwd4.hip", "selftest.hip", "capi.hip", "dwconv.hip", "merge.hip", "split.hip", "layernorm.hip", "gemm_split.hip", "upsample.hip", "pointwise.hip"]
+SOURCES = ["scan_fwd.hip", "scan_fwd4.hip", "scan_fwdr.hip", "scan_bwdr.hip", "scan_bwd.hip", "scan_bwd2.hip", "scan_bwd3.hip", "scan_bwd4.hip", "selftest.hip", "capi.hip", "dwconv.hip", "merge.hip", "layernorm.hip", "gemm_split.hip", "upsample.hip", "pointwise.hip"]
 HEADERS = ["scan_device.h", "scan_launch.h", "scan_quad.h", "scan_rowlane.h", os.path.join("..", "..", "include", "sigma_scan.h"),
            os.path.join("..", "..", "include", "sigma_ops.h"), os.path.join("..", "..", "include", "sigma_gemm.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

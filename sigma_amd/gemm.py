@@ -197,8 +197,5 @@ def enable_split3_linears(model: nn.Module, min_dim: int = MIN_DIM) -> int:
 
 
 def gemm_mode() -> str:
-    """'split3' (default): the hand-written kernels; 'fp32': vendor fp32 GEMMs (round-2 path); 'split_lib': the
-    round-2 experiment with operand images in HBM + hipBLASLt bf16 (sigma_amd/split_linear.py)."""
-    if os.environ.get("SIGMA_SPLIT_GEMM", "0") == "1":
-        return "split_lib"
+    """'split3' (default): the hand-written kernels; 'fp32': vendor fp32 GEMMs (the round-2 path)."""
     return os.environ.get("SIGMA_GEMM", "split3")

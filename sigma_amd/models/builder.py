@@ -66,15 +66,12 @@ class EncoderDecoder(nn.Module):
         if self.criterion:
             self.init_weights(cfg, pretrained=getattr(cfg, "pretrained_model", None))
         # nn.Linear GEMMs: hand-written split-operand bf16 MFMA kernels (sigma_amd/gemm.py, csrc/gemm_split.hip);
-        # SIGMA_GEMM=fp32 keeps the vendor fp32 GEMMs, SIGMA_SPLIT_GEMM=1 the round-2 library variant (split_linear.py)
+        # SIGMA_GEMM=fp32 keeps the vendor fp32 GEMMs
         from ..gemm import enable_split3_linears, gemm_mode
         self.gemm_mode = gemm_mode()
         self.split_linears = 0
         if self.gemm_mode == "split3":
             self.split_linears = enable_split3_linears(self)
-        elif self.gemm_mode == "split_lib":
-            from ..split_linear import enable_split_linears
-            self.split_linears = enable_split_linears(self)
 
     def init_weights(self, cfg, pretrained=None):
         if pretrained:

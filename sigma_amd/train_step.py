@@ -57,7 +57,26 @@ def make_optimizer(model: nn.Module, lr: float = 6e-5, weight_decay: float = 0.0
     groups = group_weight(model, lr, include_raw_params)
     on_gpu = any(p.is_cuda for g in groups for p in g["params"])
     extra = dict(fused=True, capturable=capturable) if on_gpu else {}
+    if on_gpu and capturable:
+        # A captured optimizer step replays whatever learning rate it was captured with: a Python float is baked into
+        # the graph, and the reference rewrites param_groups[i]['lr'] every iteration (WarmUpPolyLR, train.py:173-177).
+        # As a device tensor the rate is read at replay time: ``set_lr`` (below) writes the schedule's value into it.
+        dev = next(p.device for g in groups for p in g["params"] if p.is_cuda)
+        for g in groups:
+            g["lr"] = torch.tensor(float(lr), device=dev, dtype=torch.float32)
+        lr = torch.tensor(float(lr), device=dev, dtype=torch.float32)
     return torch.optim.AdamW(groups, lr=lr, betas=(0.9, 0.999), weight_decay=weight_decay, **extra)
+
+
+def set_lr(opt, lr: float) -> None:
+    """The reference's per-iteration ``optimizer.param_groups[i]['lr'] = lr`` (train.py:173-177) for optimizers of
+    ``make_optimizer``: tensor rates (capturable, i.e. graph-replayed steps) are written in place so that the next
+    replay reads the new value; float rates are replaced."""
+    for g in opt.param_groups:
+        if torch.is_tensor(g["lr"]):
+            g["lr"].fill_(float(lr))
+        else:
+            g["lr"] = float(lr)
 
 
 def _distributed() -> bool:
@@ -133,6 +152,7 @@ def make_graphed_step(net: nn.Module, opt, batch: Tuple[torch.Tensor, ...], warm
         return loss
     step.graph = graph
     step.static = static            # the graph reads these buffers: they live as long as the step does
+    step.set_lr = lambda lr: set_lr(opt, lr)      # edits of param_groups[i]['lr'] with a float would be ignored by the replay
     return step, static
 
 
@@ -177,13 +197,18 @@ def make_graphed_ddp_step(model: nn.Module, opt, batch: Tuple[torch.Tensor, ...]
         graph B: fused AdamW step
 
     `model` is the UNWRAPPED module (its parameters are broadcast from rank 0 here, as DDP's constructor does); the
-    optimizer must have been built with capturable=True.  Returns (step, static_batch)."""
+    optimizer must have been built with capturable=True (``make_optimizer``: its learning rate is then a device tensor,
+    ``step.set_lr(v)`` feeds the schedule; float edits of param_groups would be ignored by the replay).  Optimizer state
+    from earlier un-synchronised steps is discarded here, so that the replicas start identical.  ``step()`` returns the
+    local loss; ``step.reduced_loss`` holds the mean over the ranks the reference logs (train.py:168-170).
+    Returns (step, static_batch)."""
     if not _distributed():
         raise RuntimeError("make_graphed_ddp_step needs an initialised process group (world size 1 is fine)")
     for p in model.parameters():
         dist.broadcast(p.data, 0)
     for b in model.buffers():
         dist.broadcast(b.data, 0)
+    opt.state.clear()               # exp_avg / exp_avg_sq / step of steps taken before the broadcast are rank-specific
     static = tuple(t.clone() for t in batch)
     flat = flatten_grads(model)
     side = torch.cuda.Stream()
@@ -208,13 +233,18 @@ def make_graphed_ddp_step(model: nn.Module, opt, batch: Tuple[torch.Tensor, ...]
     with torch.cuda.graph(g_opt, pool=g_fb.pool(), capture_error_mode="thread_local"):
         opt.step()
 
+    world = dist.get_world_size()
+
     def step():
         g_fb.replay()
         red = loss.detach().clone()                          # train.py:168 (logging all-reduce)
         dist.all_reduce(red, op=dist.ReduceOp.SUM)
+        step.reduced_loss = red / world
         _allreduce_mean(flat, bf16_comm)
         g_opt.replay()
         return loss
+    step.reduced_loss = None
+    step.set_lr = lambda lr: set_lr(opt, lr)
     step.graphs = (g_fb, g_opt)
     step.flat = flat
     step.static = static            # the graphs read these buffers: they live as long as the step does
@@ -281,6 +311,18 @@ def launch_plan(gpus, env, n_devices: int, argv, script: str, port: int):
     cmd = [_sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), script, *argv]
     return ("spawn", cmd)
+
+
+def spawn_env(env) -> dict:
+    """Environment of the N ranks `python bench.py --gpus N` starts: the caller's, plus the switch without which RCCL /
+    device-memory sharing across processes fails on this platform (`hipIpcGetMemHandle: invalid argument`: the host
+    driver only supports dmabuf IPC) unless the caller has set it, and a loopback rendezvous (the container hostname
+    may not resolve).  Each rank then binds GPU LOCAL_RANK (``launch_plan`` returns it; bench.py calls
+    ``torch.cuda.set_device(local)`` before anything touches the device).  Reference: train.py:59-63."""
+    out = dict(env)
+    out.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    out.setdefault("MASTER_ADDR", "127.0.0.1")
+    return out
 
 
 def throughput(per_rank_batch: int, world: int, steps: int, elapsed: float) -> float:

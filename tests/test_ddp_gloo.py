@@ -150,3 +150,73 @@ def test_optimizer_groups_reference_quirk_and_opt_in_fix():
     g2 = ts.group_weight(m, 1e-3, include_raw_params=True)
     assert ts.unoptimized_parameters(m, g2) == 0 and len(g2[1]["params"]) == len(g[1]["params"]) + 2
     assert g2[1]["weight_decay"] == 0.0
+
+
+def _flat_worker(rank, world, port, out, bf16):
+    """the arithmetic of the GRAPHED data-parallel step (train_step.flatten_grads + _allreduce_mean around a plain
+    forward / backward) next to the eager DistributedDataParallel step, on the same replicas and batches"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(0)
+        model = TinySeg()
+        flat = ts.flatten_grads(model)
+        views_ok = all(p.grad.data_ptr() >= flat.data_ptr() and p.grad.data_ptr() < flat.data_ptr() + 4 * flat.numel()
+                       for p in model.parameters())
+        flat.zero_()
+        model(*_batch(rank)).backward()
+        ts._allreduce_mean(flat, bf16)
+        mine = {n: p.grad.detach().clone() for n, p in model.named_parameters()}
+        torch.manual_seed(0)
+        ref = TinySeg()
+        net = ts.wrap_ddp(ref, torch.device("cpu"))
+        net(*_batch(rank)).backward()                       # DDP: bucketed all-reduce, mean over the ranks (train.py:107)
+        theirs = {n: p.grad.detach().clone() for n, p in ref.named_parameters()}
+        torch.save(dict(mine=mine, theirs=theirs, views_ok=views_ok), out + f".r{rank}")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+@pytest.mark.parametrize("bf16", [False, True], ids=["fp32-wire", "bf16-wire"])
+def test_flat_gradient_all_reduce_equals_ddp_average_on_two_ranks(tmp_path, bf16):
+    """the world > 1 arithmetic of make_graphed_ddp_step -- every gradient a view of ONE flat buffer,
+    one all-reduce (sum) of it, division by the world size, optionally bf16 on the wire -- against DDP's average, on two
+    gloo ranks with different batches."""
+    out = str(tmp_path / "flat")
+    mp.spawn(_flat_worker, args=(2, _free_port(), out, bf16), nprocs=2, join=True)
+    r0, r1 = torch.load(out + ".r0"), torch.load(out + ".r1")
+    assert r0["views_ok"] and r1["views_ok"]
+    for n in r0["mine"]:
+        torch.testing.assert_close(r0["mine"][n], r1["mine"][n], rtol=0, atol=0)          # identical on both ranks
+        scale = float(r0["theirs"][n].abs().max()) + 1e-12
+        tol = 1.6e-2 if bf16 else 1e-6                       # bf16: 8 significant bits per addend (2^-8 relative) on the wire
+        assert float((r0["mine"][n] - r0["theirs"][n]).abs().max()) <= tol * scale, n
+
+
+def test_spawned_ranks_get_the_ipc_switch_and_a_loopback_rendezvous():
+    """what `python bench.py --gpus N` hands its N ranks (train_step.spawn_env) and how a rank binds
+    its device (launch_plan -> local rank)."""
+    env = ts.spawn_env({"PATH": "/usr/bin"})
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and env["MASTER_ADDR"] == "127.0.0.1" and env["PATH"] == "/usr/bin"
+    assert ts.spawn_env({"HSA_ENABLE_IPC_MODE_LEGACY": "1"})["HSA_ENABLE_IPC_MODE_LEGACY"] == "1"     # the caller's choice wins
+    for rank in range(8):
+        kind, world, r, local = ts.launch_plan(8, dict(WORLD_SIZE="8", RANK=str(rank), LOCAL_RANK=str(rank)), 8, [], "b", 1)
+        assert (kind, world, r, local) == ("run", 8, rank, rank)
+    import inspect
+    import bench
+    src = inspect.getsource(bench.main)
+    assert "ts.spawn_env(os.environ)" in src and "torch.cuda.set_device(local)" in src
+
+
+def test_capturable_optimizer_takes_the_schedule_through_a_tensor():
+    """ADVICE r3: a replayed optimizer step reads its learning rate at replay time only if the rate is a tensor;
+    set_lr writes into it (and replaces plain floats)."""
+    m = TinySeg()
+    opt = ts.make_optimizer(m, lr=1e-2)
+    ts.set_lr(opt, 5e-3)
+    assert all(g["lr"] == 5e-3 for g in opt.param_groups)
+    g0 = opt.param_groups[0]
+    g0["lr"] = torch.tensor(1e-2)
+    ts.set_lr(opt, 2.5e-3)
+    assert torch.is_tensor(g0["lr"]) and abs(float(g0["lr"]) - 2.5e-3) < 1e-9
