@@ -10,7 +10,10 @@ copy and a CPU ``cv2.resize`` of the class scores per scale.  Here:
 * every window of a scale is cut from ONE normalised, padded device image and the windows go through the network
   as batches (``scale_process_rgbX``: window batch x flip = up to ``2 * max_windows`` images per forward);
 * the window scores are accumulated on the device and resized there (``F.interpolate``, bilinear,
-  ``align_corners=False`` = cv2's INTER_LINEAR sampling grid); only the final (H, W, classes) array goes to the host.
+  ``align_corners=False`` = cv2's INTER_LINEAR sampling grid for float data); only the final (H, W, classes) array goes
+  to the host;
+* the per-scale resize of the uint8 inputs (``sliding_eval_rgbX``, engine/evaluator.py:438-446) runs on the device in
+  cv2's own integer arithmetic (``resize_like_cv2``), so the network sees the bytes the reference's loop would feed it.
 
 Drop-in for the reference's ``Evaluator`` (same method names, arguments and return values):
 
@@ -19,10 +22,12 @@ Drop-in for the reference's ``Evaluator`` (same method names, arguments and retu
     evaluator.sliding_eval_rgbX = types.MethodType(evaluator_ops.sliding_eval_rgbX, evaluator)
 
 The window grid reproduces the reference's arithmetic literally, including its mixed use of ``crop_size[0]`` /
-``stride[0]`` for the column direction (evaluator.py:472-478): a drop-in must score the same pixels.  With the
-reference's configurations (``eval_scale_array = [1]``) nothing is resized before the network, so the scores are those
-of the reference loop to rounding; at other scales cv2's fixed-point uint8 resize differs from the float resize used
-here in the last bit of some input pixels.
+``stride[0]`` for the column direction (evaluator.py:472-478): a drop-in must score the same pixels.  With a crop that
+is not square that arithmetic produces NEGATIVE window starts once the scaled image is larger than the crop -- NYU /
+SUN-RGBD evaluate at ``eval_scale_array = [0.75, 1, 1.25]`` with ``eval_crop_size = [480, 640]`` and ``eval_flip``
+(configs/config_nyu.py:114-117; MFNet and PST900 use ``[1]``), and at 1.25 the 600 x 800 image gets row windows
+``[-40:600]`` -- which numpy and torch slicing wrap to the LAST 40 rows; the reference therefore scores only those rows
+at that scale.  ``window_grid`` resolves the slices the same way, so the sum over the scales is the reference's.
 """
 from __future__ import annotations
 
@@ -77,10 +82,17 @@ def _normalized_planes(img: np.ndarray, mean, std, device) -> torch.Tensor:
     return torch.from_numpy(np.ascontiguousarray(arr.transpose(2, 0, 1), dtype=np.float32)).cuda(device)
 
 
+def _as_slice(start: int, stop: int, size: int):
+    """what ``array[start:stop]`` selects on an axis of `size` (negative indices count from the end, as numpy's and
+    torch's slicing do for the reference's img_pad[s_y:e_y, s_x:e_x] and data_scale[:, s_y:e_y, s_x:e_x])"""
+    lo, hi, _ = slice(start, stop).indices(size)
+    return lo, max(lo, hi)
+
+
 def window_grid(pad_rows: int, pad_cols: int, crop, stride_rate: float):
     """(s_y, e_y, s_x, e_x) of every window, in the reference's order and with its index arithmetic
     (engine/evaluator.py:464-478: the column direction uses stride[0] / crop_size[0], the row direction stride[1] /
-    crop_size[1])."""
+    crop_size[1]); a negative start is resolved as the reference's slicing resolves it (module docstring)."""
     stride = (int(np.ceil(crop[0] * stride_rate)), int(np.ceil(crop[1] * stride_rate)))
     r_grid = int(np.ceil((pad_rows - crop[0]) / stride[0])) + 1
     c_grid = int(np.ceil((pad_cols - crop[1]) / stride[1])) + 1
@@ -90,9 +102,10 @@ def window_grid(pad_rows: int, pad_cols: int, crop, stride_rate: float):
             s_x, s_y = gx * stride[0], gy * stride[1]
             e_x, e_y = min(s_x + crop[0], pad_cols), min(s_y + crop[1], pad_rows)
             s_x, s_y = e_x - crop[0], e_y - crop[1]
-            if s_x < 0 or s_y < 0:
-                raise ValueError(f"window start ({s_y}, {s_x}) is negative: the reference's slicing would wrap around "
-                                 f"(padded image {pad_rows}x{pad_cols}, crop {tuple(crop)})")
+            (s_y, e_y), (s_x, e_x) = _as_slice(s_y, e_y, pad_rows), _as_slice(s_x, e_x, pad_cols)
+            if e_y == s_y or e_x == s_x:
+                raise ValueError(f"empty window (padded image {pad_rows}x{pad_cols}, crop {tuple(crop)}): the reference's "
+                                 f"cv2.copyMakeBorder would fail on it too")
             wins.append((s_y, e_y, s_x, e_x))
     return wins
 
@@ -137,38 +150,101 @@ def scale_process_rgbX(self, img, modal_x, ori_shape, crop_size, stride_rate, de
             data_scale = torch.zeros(self.class_num, pad_rows, pad_cols, device=dev)
             for i in range(0, len(wins), max_windows):
                 chunk = wins[i:i + max_windows]
-                subs, subx, marg = [], [], None
+                subs, subx, margs = [], [], []
                 for (s_y, e_y, s_x, e_x) in chunk:
                     a, marg = padded(rgb_p[:, s_y:e_y, s_x:e_x], e_y - s_y, e_x - s_x)
                     b, _ = padded(mx_p[:, s_y:e_y, s_x:e_x], e_y - s_y, e_x - s_x)
                     subs.append(a)
                     subx.append(b)
+                    margs.append(marg)
                 sc = batch_scores(self.val_func, torch.stack(subs), torch.stack(subx), flip)
-                sc = sc[:, :, marg[0]:sc.shape[2] - marg[1], marg[2]:sc.shape[3] - marg[3]]
                 for k, (s_y, e_y, s_x, e_x) in enumerate(chunk):
-                    data_scale[:, s_y:e_y, s_x:e_x] += sc[k]
+                    m = margs[k]
+                    data_scale[:, s_y:e_y, s_x:e_x] += sc[k][:, m[0]:sc.shape[2] - m[1], m[2]:sc.shape[3] - m[3]]
             score = data_scale[:, top:data_scale.shape[1] - bottom, left:data_scale.shape[2] - right]
         if tuple(score.shape[1:]) != (int(ori_shape[0]), int(ori_shape[1])):
             score = F.interpolate(score[None], size=(int(ori_shape[0]), int(ori_shape[1])), mode="bilinear", align_corners=False)[0]
         return score.permute(1, 2, 0).contiguous().cpu().numpy()
 
 
-def _resize_hw(arr: np.ndarray, scale: float, nearest: bool, device) -> np.ndarray:
-    """cv2.resize(arr, None, fx=scale, fy=scale, INTER_LINEAR | INTER_NEAREST) on the device (float arithmetic)"""
-    if scale == 1:
-        return arr
-    t = torch.from_numpy(np.ascontiguousarray(arr)).to(device)
-    hw = t if t.ndim == 2 else t.permute(2, 0, 1)
-    hw = hw[None, None] if t.ndim == 2 else hw[None]
-    size = (int(round(arr.shape[0] * scale)), int(round(arr.shape[1] * scale)))
+_COEF_ONE = 1 << 11         # cv2's INTER_RESIZE_COEF_SCALE: bilinear weights of 8-bit images are 11-bit fixed point
+
+
+def _sample_table(dst: int, src: int, inv_scale: float):
+    """Host-side tables of cv::resize's linear path (tiny: one entry per destination row / column, built on the host by
+    cv2 as well): source index floor((d + 0.5) / inv_scale - 0.5), evaluated in double and held in float32, and the
+    float32 weight of the next sample."""
+    pos = ((np.arange(dst, dtype=np.float64) + 0.5) * (1.0 / inv_scale) - 0.5).astype(np.float32)
+    base = np.floor(pos)
+    return base.astype(np.int64), (pos - base).astype(np.float32)
+
+
+def _fixed(w: np.ndarray) -> np.ndarray:
+    return np.clip(np.rint(w.astype(np.float32) * np.float32(_COEF_ONE)), -32768, 32767).astype(np.int32)
+
+
+def resize_like_cv2(arr: np.ndarray, scale: float, nearest: bool, device) -> np.ndarray:
+    """``cv2.resize(arr, None, fx=scale, fy=scale, interpolation=INTER_NEAREST if nearest else INTER_LINEAR)`` computed
+    on the device, bit for bit for uint8 (H, W) / (H, W, C) arrays (OpenCV 4.x modules/imgproc/src/resize.cpp, the
+    non-IPP path the reference's evaluation runs; oracle/evaluator_oracle.py restates it one pixel at a time):
+    destination size round-half-even(src * scale); INTER_NEAREST index min(floor(d / scale), size - 1); INTER_LINEAR of
+    8-bit data with 11-bit fixed-point weights, an int32 horizontal pass and the vertical pass
+    (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2; a factor of exactly 1/2 is cv2's 2 x 2 area mean.
+    Float32 arrays take the same sampling grid in float arithmetic (not bit-exact: cv2 may use IPP there)."""
+    sh, sw = arr.shape[0], arr.shape[1]
+    dh, dw = int(np.rint(sh * float(scale))), int(np.rint(sw * float(scale)))
+    if dh <= 0 or dw <= 0:
+        raise ValueError(f"cv2.resize of a {sh}x{sw} image by {scale} has no pixels")
+    if (dh, dw) == (sh, sw):
+        return arr.copy()
+    if arr.dtype not in (np.uint8, np.float32) and not nearest:
+        raise TypeError(f"resize_like_cv2: INTER_LINEAR is restated for uint8 and float32 images, got {arr.dtype}")
+    src = torch.from_numpy(np.ascontiguousarray(arr if arr.ndim == 3 else arr[:, :, None])).to(device)
+
+    def dev(a, dtype):
+        return torch.as_tensor(a, dtype=dtype, device=device)
+
+    inv = float(scale)
     if nearest:
-        out = F.interpolate(hw.float(), size=size, mode="nearest")
+        xs = np.minimum(np.floor(np.arange(dw) * (1.0 / inv)).astype(np.int64), sw - 1)
+        ys = np.minimum(np.floor(np.arange(dh) * (1.0 / inv)).astype(np.int64), sh - 1)
+        out = src.index_select(0, dev(ys, torch.long)).index_select(1, dev(xs, torch.long))
+    elif arr.dtype == np.uint8 and abs(1.0 / inv - 2.0) < np.finfo(np.float64).eps:
+        # cv::resize turns INTER_LINEAR into the fast INTER_AREA for an exact 2 x 2 reduction
+        px = F.pad(src.permute(2, 0, 1).to(torch.int32), (0, 2 * dw - sw if 2 * dw > sw else 0, 0, 2 * dh - sh if 2 * dh > sh else 0))
+        px = px[:, :2 * dh, :2 * dw]
+        ones = torch.zeros(1, px.shape[1], px.shape[2], dtype=torch.int32, device=device)
+        ones[:, :sh, :sw] = 1
+        cells = lambda t: t[:, 0::2, 0::2] + t[:, 0::2, 1::2] + t[:, 1::2, 0::2] + t[:, 1::2, 1::2]
+        total, count = cells(px), cells(ones)
+        # a cell counts as "full" where cv2's fast loop covers it: both rows inside and dx < src_width / 2
+        full = count == 4
+        mean = torch.round(total.float() / count.clamp(min=1).float()).to(torch.int32)
+        out = torch.where(full, (total + 2) >> 2, torch.where(count > 0, mean, torch.zeros_like(total)))
+        out = out.clamp_(0, 255).to(torch.uint8).permute(1, 2, 0)
     else:
-        out = F.interpolate(hw.float(), size=size, mode="bilinear", align_corners=False)
-    if arr.dtype == np.uint8:
-        out = out.round().clamp_(0, 255)
-    out = out[0, 0] if t.ndim == 2 else out[0].permute(1, 2, 0)
-    return out.to(t.dtype).cpu().numpy()
+        xb, xt = _sample_table(dw, sw, inv)
+        yb, yt = _sample_table(dh, sh, inv)
+        edge = (xb < 0) | (xb >= sw - 1)                 # columns: index clamped AND the weight pair forced to (1, 0)
+        xt = np.where(edge, np.float32(0), xt)
+        x0 = np.clip(xb, 0, sw - 1)
+        x1 = np.minimum(x0 + 1, sw - 1)
+        y0, y1 = np.clip(yb, 0, sh - 1), np.clip(yb + 1, 0, sh - 1)      # rows: indices clipped, weights kept
+        if arr.dtype == np.uint8:
+            a0, a1 = dev(_fixed(np.float32(1) - xt), torch.int32), dev(_fixed(xt), torch.int32)
+            b0, b1 = dev(_fixed(np.float32(1) - yt), torch.int32), dev(_fixed(yt), torch.int32)
+            s32 = src.to(torch.int32)
+            rows = s32.index_select(1, dev(x0, torch.long)) * a0[None, :, None] + s32.index_select(1, dev(x1, torch.long)) * a1[None, :, None]
+            rows = rows >> 4
+            out = (((rows.index_select(0, dev(y0, torch.long)) * b0[:, None, None]) >> 16)
+                   + ((rows.index_select(0, dev(y1, torch.long)) * b1[:, None, None]) >> 16) + 2) >> 2
+            out = out.clamp_(0, 255).to(torch.uint8)
+        else:
+            a1, b1 = dev(xt, torch.float32), dev(yt, torch.float32)
+            rows = src.index_select(1, dev(x0, torch.long)) * (1 - a1)[None, :, None] + src.index_select(1, dev(x1, torch.long)) * a1[None, :, None]
+            out = rows.index_select(0, dev(y0, torch.long)) * (1 - b1)[:, None, None] + rows.index_select(0, dev(y1, torch.long)) * b1[:, None, None]
+    out = out.contiguous().cpu().numpy()
+    return out[:, :, 0] if arr.ndim == 2 else out
 
 
 def sliding_eval_rgbX(self, img, modal_x, crop_size, stride_rate, device=None):
@@ -178,7 +254,7 @@ def sliding_eval_rgbX(self, img, modal_x, crop_size, stride_rate, device=None):
     processed = np.zeros((ori_rows, ori_cols, self.class_num))
     dev = torch.device("cuda", torch.cuda.current_device() if device is None else device)
     for s in self.multi_scales:
-        img_scale = _resize_hw(img, s, False, dev)
-        mx_scale = _resize_hw(modal_x, s, modal_x.ndim == 2, dev)
+        img_scale = resize_like_cv2(img, s, False, dev)
+        mx_scale = resize_like_cv2(modal_x, s, modal_x.ndim == 2, dev)
         processed += scale_process_rgbX(self, img_scale, mx_scale, (ori_rows, ori_cols), crop, stride_rate, device)
     return processed.argmax(2)

@@ -127,10 +127,12 @@ def test_evaluator_window_grid_reproduces_the_reference_arithmetic():
     for s_y, e_y, s_x, e_x in wins:
         covered[s_y:e_y, s_x:e_x] = True
     assert covered.all()
-    # a non-square crop on an image that is shorter than crop[1]: the reference's mixed indices give a negative start (its
-    # numpy slicing would silently wrap around); here that is an error instead of wrong scores
-    with pytest.raises(ValueError):
-        window_grid(600, 800, (480, 640), 2 / 3)
+    # a non-square crop on an image that is shorter than crop[1] (NYU at scale 1.25): the reference's mixed indices give a
+    # negative start, which its numpy / torch slicing wraps to the end of the axis -- reproduced, since a drop-in must
+    # score the same pixels (tests/test_evaluator_oracle.py has the window list)
+    img = np.arange(600 * 800).reshape(600, 800)
+    for (s_y, e_y, s_x, e_x) in window_grid(600, 800, (480, 640), 2 / 3):
+        assert s_y >= 0 and np.array_equal(img[s_y:e_y, s_x:e_x], img[e_y - 640:e_y, e_x - 480:e_x])
 
 
 def test_gemm_and_gate_wrappers_refuse_cpu_tensors():
