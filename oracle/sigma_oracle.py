@@ -35,7 +35,24 @@ def _ln(x, sd: SD, prefix: str):
     return F.layer_norm(x, (w.numel(),), w, sd[prefix + ".bias"], 1e-5)
 
 
+class _ScanWithGrad(torch.autograd.Function):
+    """the C oracle's forward and backward recurrences (oracle/scan_oracle.c) as one autograd node, for sigma_gradients"""
+
+    @staticmethod
+    def forward(ctx, u, delta, A, B, C, D, bias):
+        ctx.save_for_backward(u, delta, A, B, C, D, bias)
+        return scan_oracle.selective_scan_oracle(u, delta, A, B, C, D, bias, True, acc64=False)
+
+    @staticmethod
+    def backward(ctx, dout):
+        u, delta, A, B, C, D, bias = ctx.saved_tensors
+        du, dd, dA, dB, dC, dD, db = scan_oracle.selective_scan_oracle_bwd(u, delta, A, B, C, D, bias, dout.contiguous(), True)
+        return du, dd, dA, dB, dC, dD, db
+
+
 def _scan(u, delta, A, B, C, D, bias):
+    if torch.is_grad_enabled() and any(t.requires_grad for t in (u, delta, A, B, C, D, bias)):
+        return _ScanWithGrad.apply(u.contiguous(), delta.contiguous(), A.contiguous(), B.contiguous(), C.contiguous(), D, bias)
     return scan_oracle.selective_scan_oracle(u, delta, A, B, C, D, bias, True, acc64=False)
 
 
@@ -232,16 +249,41 @@ def decoder(feats, sd: SD):
 
 
 # ---- EncoderDecoder.encode_decode / forward, models/builder.py:128-157
+def _logits(sd: SD, rgb, modal_x, backbone):
+    feats = encoder(rgb, modal_x, sd, PRESETS[backbone]["depths"])
+    out = decoder(feats, sd)
+    return F.interpolate(out, size=rgb.shape[2:], mode="bilinear", align_corners=False), feats
+
+
 @torch.no_grad()
 def sigma_forward(sd: SD, rgb: torch.Tensor, modal_x: torch.Tensor, backbone: str = "sigma_tiny",
                   return_features: bool = False):
     """Logits (B, num_classes, H, W) of the reference model in eval mode, on CPU, fp32."""
     sd = {k: v.detach().to("cpu", torch.float32) for k, v in sd.items()}
     rgb, modal_x = rgb.detach().cpu().float(), modal_x.detach().cpu().float()
-    feats = encoder(rgb, modal_x, sd, PRESETS[backbone]["depths"])
-    out = decoder(feats, sd)
-    out = F.interpolate(out, size=rgb.shape[2:], mode="bilinear", align_corners=False)
+    out, feats = _logits(sd, rgb, modal_x, backbone)
     return (out, feats) if return_features else out
+
+
+def sigma_gradients(sd: SD, rgb, modal_x, label, backbone: str = "sigma_tiny", names=None):
+    """(logits, loss, {name: d loss / d parameter}) of the restated model: torch autograd over the plain functions of
+    this file, the scans differentiated by the C oracle's backward recurrence (scan_oracle.c).  `names` = the state-dict
+    entries that are parameters (default: every floating-point entry).  Independent of sigma_amd's modules, so it
+    also catches host-side wiring mistakes of their backward (checkpoint hand-offs, merged projections, fused
+    operators).  Pinned by tests/test_oracle_model.py against the reference's own gradient digests."""
+    leaves = {}
+    for k, v in sd.items():
+        t = v.detach().to("cpu", torch.float32).clone()
+        if v.is_floating_point() and (names is None or k in names):
+            t.requires_grad_(True)
+        leaves[k] = t
+    rgb, modal_x = rgb.detach().cpu().float(), modal_x.detach().cpu().float()
+    with torch.enable_grad():
+        out, _ = _logits(leaves, rgb, modal_x, backbone)
+        loss = F.cross_entropy(out, label.cpu().long(), ignore_index=255)
+        loss.backward()
+    grads = {k: t.grad for k, t in leaves.items() if t.requires_grad}
+    return out.detach(), loss.detach(), grads
 
 
 def sigma_loss(sd: SD, rgb, modal_x, label, backbone: str = "sigma_tiny") -> torch.Tensor:

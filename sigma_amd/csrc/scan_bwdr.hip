@@ -169,7 +169,11 @@ __device__ __forceinline__ void scan_bwdr_body(const BwdArgs& q, float* smem, co
     const int ntiles = (L + T - 1) / T;
     v4f* sProc = reinterpret_cast<v4f*>(smem);                    // [5][4][64] float4: delta, delta * u, dout; u, softplus' (epilogue)
     v4f* sEx = sProc + 5 * 256;                                   // [4 waves][2][4][64] float4: sum dx B, sum A2 dx a x_prev
+#if SIGMA_RL_ABL & 128
+    v4f* sRaw = sEx + 4 * 256;
+#else
     v4f* sRaw = sEx + 8 * 256;                                    // [3][256 threads] float4: u, delta, dout of the NEXT tile (LDS-DMA)
+#endif
     const unsigned raw_base = (unsigned)(uintptr_t)(lptr_t)(sRaw + sw * 64);   // this wave's 1 KB of array 0
 
     // thread as (row, chunk)
@@ -464,8 +468,13 @@ __device__ __forceinline__ void scan_bwdr_body(const BwdArgs& q, float* smem, co
             for (int c = 0; c < 2; ++c) {
                 const v4f t1 = {sdxB[4 * c], sdxB[4 * c + 1], sdxB[4 * c + 2], sdxB[4 * c + 3]};
                 const v4f t2 = {sAx[4 * c], sAx[4 * c + 1], sAx[4 * c + 2], sAx[4 * c + 3]};
+#if SIGMA_RL_ABL & 128
+                sEx[((sw & 1) * 2) * 256 + rl_unit(2 * hm + c, lane)] = t1;
+                sEx[((sw & 1) * 2 + 1) * 256 + rl_unit(2 * hm + c, lane)] = t2;
+#else
                 sEx[(sw * 2) * 256 + rl_unit(2 * hm + c, lane)] = t1;
                 sEx[(sw * 2 + 1) * 256 + rl_unit(2 * hm + c, lane)] = t2;
+#endif
             }
 #endif
             if (hs == 1) {                                          // entering the second scan half of the NEXT step
@@ -481,7 +490,7 @@ __device__ __forceinline__ void scan_bwdr_body(const BwdArgs& q, float* smem, co
             v4f S1 = {0.0f, 0.0f, 0.0f, 0.0f}, S2 = {0.0f, 0.0f, 0.0f, 0.0f};
 #if !(SIGMA_RL_ABL & 16)
 #pragma unroll
-            for (int w = 0; w < 4; ++w) { S1 += sEx[(w * 2) * 256 + rl_unit(cc, rr)]; S2 += sEx[(w * 2 + 1) * 256 + rl_unit(cc, rr)]; }
+            for (int w = 0; w < 4; ++w) { S1 += sEx[((w & (SIGMA_RL_ABL & 128 ? 1 : 3)) * 2) * 256 + rl_unit(cc, rr)]; S2 += sEx[((w & (SIGMA_RL_ABL & 128 ? 1 : 3)) * 2 + 1) * 256 + rl_unit(cc, rr)]; }
 #endif
             const v4f dle = sProc[rl_unit(cc, rr)], ge = sProc[512 + rl_unit(cc, rr)];
             const v4f ue = sProc[768 + rl_unit(cc, rr)], sge = sProc[1024 + rl_unit(cc, rr)];

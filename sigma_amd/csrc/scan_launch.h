@@ -54,7 +54,11 @@ inline size_t fwd4_lds_bytes(int N) { return sizeof(float) * (2 * 2 * (size_t)N 
 // row-lane kernels (scan_fwdr.hip / scan_bwdr.hip): [arrays][4 chunks][64 rows] float4 of pre-processed operands +
 // [state waves][...] partial sums over the states
 inline size_t fwdr_lds_bytes(int NW) { return 16 * (size_t)(2 * 256 + NW * 256); }
+#if defined(SIGMA_RL_ABL) && (SIGMA_RL_ABL & 128)
+inline size_t bwdr_lds_bytes(int NW) { return 16 * (size_t)(5 * 256 + NW * 256 + 3 * 256); }        // timing probe: half the exchange area
+#else
 inline size_t bwdr_lds_bytes(int NW) { return 16 * (size_t)(5 * 256 + NW * 2 * 256 + 3 * 256); }
+#endif
 
 constexpr int kMaxDevices = 16;    // per-device cache of the raised dynamic-LDS cap (hipFuncSetAttribute is per device)
 

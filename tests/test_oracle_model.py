@@ -79,3 +79,27 @@ def test_host_model_logic_matches_reference(case):
         if not np.allclose(d, r, rtol=2e-3, atol=2e-3 * (abs(r[1]) / max(g.numel(), 1) + 1e-6) * g.numel() ** 0.5 + 1e-6):
             bad.append((n, d, r))
     assert not bad, bad[:5]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_oracle_gradients_match_the_reference_digests(case):
+    """oracle/sigma_oracle.sigma_gradients (autograd over the restated functions + the C oracle's scan backward) against
+    the gradient digests the reference's own model produced (tests/golden/make_golden_model.py): this pins the gradient
+    reference the 480 x 640 GPU test uses, independently of sigma_amd's modules."""
+    from oracle import sigma_oracle
+    meta, z = load_model_golden(case)
+    model = build_model(meta["backbone"], meta["num_classes"], meta["H"], meta["W"]).eval()
+    rgb, x, label = fill.make_inputs(meta["batch"], meta["H"], meta["W"], meta["num_classes"])
+    names = {n for n, _ in model.named_parameters()}
+    logits, loss, grads = sigma_oracle.sigma_gradients(model.state_dict(), rgb, x, label, meta["backbone"], names)
+    assert_logits_close(logits, torch.from_numpy(z["logits"]), 2e-5)
+    assert abs(loss.item() - float(z["loss"])) < 1e-4
+    assert sorted(grads) == sorted(z["grad_names"])
+    bad = []
+    for n, r in zip(list(z["grad_names"]), z["grad_digest"]):
+        g = grads[n]
+        assert g is not None, n
+        d = digest(g)
+        if not np.allclose(d, r, rtol=2e-3, atol=2e-3 * (abs(r[1]) / max(g.numel(), 1) + 1e-6) * g.numel() ** 0.5 + 1e-6):
+            bad.append((n, d, r))
+    assert not bad, bad[:5]

@@ -70,4 +70,11 @@ f)  # row-lane kernels under pytest + the model with the new pitch policy + benc
     ( timeout 600 python bench.py --per-gpu-batch 1 --graph --no-cpu-baseline ) > $out/bench_b1_graph.log 2>&1; grep "^{" $out/bench_b1_graph.log | cut -c1-300
     ( SIGMA_CKPT_PITCH=norowlane timeout 600 python bench.py --per-gpu-batch 1 --graph --no-cpu-baseline ) > $out/bench_b1_graph_norowlane.log 2>&1; grep "^{" $out/bench_b1_graph_norowlane.log | cut -c1-300
     ;;
+g)  # parity additions of this round (evaluator multi-scale, oracle-driven 480x640 gradients), HBM traffic of the row-lane
+    # kernels at the dominant launch shape (FETCH_SIZE / WRITE_SIZE passes only), kernel trace of the benchmark step
+    ( time timeout 1200 python -m pytest tests/test_model_gpu.py -q --tb=short -x -k "evaluator or resize or gradients_vs_cpu_oracle" ) > $out/pytest_parity.log 2>&1; tail -4 $out/pytest_parity.log | cut -c1-300
+    SCAN_BENCH_ARGS="--pitch 16" bash tools/gpu_pmc.sh r4_g/pmc enc_s2_b16 traffic > $out/pmc.txt 2>&1; grep -A3 "^== " $out/pmc.txt | grep -v "^--" | cut -c1-400
+    R=$PWD; ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/trace -o b8 -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline ) > $out/trace.log 2>&1; grep "^{" $out/trace.log | cut -c1-400
+    tr=$(find $out/trace -name "*kernel_trace.csv" | head -1); python tools/prof_summary.py $tr --top 60 --last-ms 340 > $out/trace_summary.txt 2>&1; head -70 $out/trace_summary.txt | cut -c1-200
+    ;;
 esac

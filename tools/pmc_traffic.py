@@ -33,8 +33,9 @@ def main():
             for r in csv.DictReader(open(f)):
                 if r["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
                     kn = r["Kernel_Name"]
-                    k = "scan_fwd" if ("scan_fwd_kernel" in kn or "scan_fwd4_kernel" in kn) else \
-                        "scan_bwd" if ("scan_bwd_kernel" in kn or "scan_bwd2_kernel" in kn or "scan_bwd3_kernel" in kn or "scan_bwd4_kernel" in kn) else \
+                    k = "scan_fwd" if any(t in kn for t in ("scan_fwd_kernel", "scan_fwd4_kernel", "scan_fwdr_kernel")) else \
+                        "scan_bwd" if any(t in kn for t in ("scan_bwd_kernel", "scan_bwd2_kernel", "scan_bwd3_kernel", "scan_bwd4_kernel",
+                                                            "scan_bwdr_kernel")) else \
                         "reduce_partials" if "reduce_partials" in kn else None
                     if k:
                         vals[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
