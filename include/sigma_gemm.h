@@ -44,6 +44,18 @@ typedef struct sigma_gemm_params {
                               shared by groups of problems, e.g. the 2 memory orders x B images of x_proj */
     int32_t pieces;        /* bf16 pieces per fp32 operand element: 0 or 2 = (hi, lo), three MFMAs per block, ~4e-6 rms
                               error; 3 = (hi, mid, lo), six MFMAs, ~1e-6 = the accuracy of an fp32 GEMM          */
+    /* ABI 8: fused epilogue inputs and shared outputs (nt / nn only)                                            */
+    int32_t c_mod;         /* > 0: problem z writes C + (z % c_mod) * strideC and the problems that share an output are
+                              SUMMED into it with fp32 atomics (the caller zero-fills C, or passes accumulate = 1):
+                              weight gradients of a stacked projection summed over the batch, e.g. d x_proj_weight =
+                              sum_b dp[b] xs[b]^T (vmamba.py:193-196 under autograd)                                */
+    int32_t reserved;      /* 0 */
+    const float *residual; /* (M, N) per problem, element (m, n) at residual[z * strideR + m * ldr + n], or NULL:
+                              C = A B (+ bias) + residual (+ residual2) -- the residual stream of a block added in the
+                              GEMM epilogue (x + out_proj(y), vmamba.py:1716-1722) or the two per-direction input
+                              gradients of the scan joined with the projection's (dxs = W^T dp + du[dir] + du[dir^1]) */
+    const float *residual2;/* second addend with the same ldr / strideR, or NULL                                       */
+    int64_t ldr, strideR;
 } sigma_gemm_params;
 
 /*   sigma_gemm_nt_split3

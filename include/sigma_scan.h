@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SIGMA_SCAN_ABI_VERSION 7
+#define SIGMA_SCAN_ABI_VERSION 8
 
 /* dtype of u, delta, B, C, out, dout, du, ddelta  (input_t of the reference,
  * selective_scan.cpp:174: float / half / bfloat16).  A, D, delta_bias, x, dA,

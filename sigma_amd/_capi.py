@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SIGMA_HIP_LIB lets a benchmark A/B an experimental build of the same ABI; default is the in-tree library
 LIB_PATH = os.environ.get("SIGMA_HIP_LIB") or os.path.join(_HERE, "lib", "libsigma_hip.so")
 
-SIGMA_SCAN_ABI_VERSION = 7
+SIGMA_SCAN_ABI_VERSION = 8
 SIGMA_SCAN_CHUNK = 2048
 SIGMA_SCAN_CKPT_PITCH = 1280
 SIGMA_SCAN_CKPT_PITCH_FINE = 640
@@ -121,6 +121,8 @@ class GemmParams(ctypes.Structure):
         ("accumulate", ctypes.c_int32), ("batch", ctypes.c_int32),
         ("strideA", ctypes.c_int64), ("strideB", ctypes.c_int64), ("strideC", ctypes.c_int64),
         ("a_mod", ctypes.c_int32), ("pieces", ctypes.c_int32),
+        ("c_mod", ctypes.c_int32), ("reserved", ctypes.c_int32),
+        ("residual", ctypes.c_void_p), ("residual2", ctypes.c_void_p), ("ldr", ctypes.c_int64), ("strideR", ctypes.c_int64),
     ]
 
 

@@ -57,6 +57,9 @@ struct GemmArgs {
     int batch;              // problems
     int mode;               // 0: C = ..., 1: C += ... (plain), 2: atomicAdd (slices > 1)
     int a_mod;              // > 0: A of batch z is A + (z % a_mod) * sA  (weights shared by groups of problems)
+    int c_mod;              // > 0: C of batch z is C + (z % c_mod) * sC  (mode 2: the problems sharing it are summed)
+    const float* R; const float* R2;   // epilogue addends (or null), row stride ldr, batch stride sR
+    long ldr, sR;
 };
 
 // P bf16 pieces of two floats (packed pairs): piece[0] = bf16(x), piece[1] = bf16(x - piece[0]), piece[2] = bf16 of the
@@ -129,6 +132,11 @@ struct TileLoader {
         return;
 #endif
         const unsigned ldb4 = (unsigned)(ld * 4);
+        // the base is wave-uniform by construction; readfirstlane folds away when the compiler knows it and keeps the
+        // "s" operand of the asm legal when it does not (it then holds the pointer in VGPRs)
+        const uintptr_t bq = reinterpret_cast<uintptr_t>(base);
+        base = reinterpret_cast<const float*>(((uintptr_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(bq >> 32)) << 32) |
+                                              (unsigned)__builtin_amdgcn_readfirstlane((int)(bq & 0xffffffffu)));
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             unsigned o = KS ? off[i >> 2] + (unsigned)(i & 3) * ldb4 : off[i];
@@ -150,11 +158,13 @@ struct TileLoader {
     __device__ __forceinline__ void store(const f32x4_t (&v)[NV], int rem, uint16_t* __restrict__ img, int img_stride) const {
         const int t = threadIdx.x;
         if constexpr (!KS) {
-            const bool ok = ((t & 7) << 2) < rem;
+            // only the last, partial k-step of a reduction masks (wave-uniform branch: the full step carries no selects)
+            const bool ok = rem >= kBK || ((t & 7) << 2) < rem;
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
                 const int o = ((t >> 3) + 32 * i) * kPitch + ((t & 7) << 2);
-                const f32x4_t x = ok ? v[i] : f32x4_t{0.f, 0.f, 0.f, 0.f};
+                f32x4_t x = v[i];
+                if (rem < kBK) x = ok ? x : f32x4_t{0.f, 0.f, 0.f, 0.f};
                 unsigned p01[P], p23[P];
                 split_pair<P>(x[0], x[1], p01);
                 split_pair<P>(x[2], x[3], p23);
@@ -168,7 +178,11 @@ struct TileLoader {
                 ch = ch < ROWS / 4 ? ch : ROWS / 4 - 1;                   // repeated chunk: same values, same address
                 f32x4_t x[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) x[j] = (((t & 7) << 2) + j < rem) ? v[4 * i + j] : f32x4_t{0.f, 0.f, 0.f, 0.f};
+                for (int j = 0; j < 4; ++j) x[j] = v[4 * i + j];
+                if (rem < kBK) {                                          // wave-uniform: the last, partial k-step
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) x[j] = (((t & 7) << 2) + j < rem) ? x[j] : f32x4_t{0.f, 0.f, 0.f, 0.f};
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int o = (4 * ch + r) * kPitch + ((t & 7) << 2);
@@ -193,6 +207,9 @@ __device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" :
 #ifndef SIGMA_GEMM_DEPTH
 #define SIGMA_GEMM_DEPTH 0
 #endif
+#ifndef SIGMA_GEMM_ROW_EPILOGUE
+#define SIGMA_GEMM_ROW_EPILOGUE 1          // 0: A/B builds with the direct (dword) epilogue
+#endif
 template <bool A_KS, bool B_KS>
 struct ring_depth { static constexpr int value = SIGMA_GEMM_DEPTH ? SIGMA_GEMM_DEPTH : ((A_KS && B_KS) ? 2 : 1); };
 
@@ -200,6 +217,7 @@ struct ring_depth { static constexpr int value = SIGMA_GEMM_DEPTH ? SIGMA_GEMM_D
 struct Item {
     long m0; int n0, kbeg, kend, sl;
     const float* Ab; const float* Bb; float* Cb;
+    long r_off;             // element offset of this problem's addends
 };
 
 // Persistent workgroups: workgroup b walks the work items b, b + gridDim.x, ... (an item = one BM x BN output tile
@@ -207,7 +225,7 @@ struct Item {
 // are requested from global memory when step s is consumed -- HBM latency (~2 us under load, i.e. several k-steps of
 // MFMA time) is covered by the ring instead of by occupancy (two workgroups per CU), and the epilogue of a tile
 // overlaps the first loads of the next one.
-template <int BM, int BN, int WM, int WN, bool A_KS, bool B_KS, int P>
+template <int BM, int BN, int WM, int WN, bool A_KS, bool B_KS, int P, bool RES>
 __global__ void __launch_bounds__(256, 2)
 gemm_split3_kernel(const GemmArgs g) {
     static_assert(WM * WN == 4, "four waves");
@@ -229,7 +247,9 @@ gemm_split3_kernel(const GemmArgs g) {
     // item id -> (batch, row tile, column tile, slice); ids that are consecutive after the XCD remap (column tiles and
     // slices of one row tile) run on the same XCD at about the same time: the A tile is re-read from that XCD's L2
     auto decode = [&](int id, Item& it) {
-        const int lbk = xcd_logical_block(id, total);
+        // the item index is wave-uniform by construction (workgroup id + k * grid); said explicitly, so that everything
+        // derived from it (tile origin, operand bases -> the SGPR operands of the asm loads) stays on the scalar unit
+        const int lbk = __builtin_amdgcn_readfirstlane(xcd_logical_block(id, total));
         const int z = lbk / per_z;
         const int r0 = lbk - z * per_z;
         const int tm_i = r0 / (g.ntn * g.slices);
@@ -242,7 +262,8 @@ gemm_split3_kernel(const GemmArgs g) {
         it.kend = (it.kbeg + g.slice_k < g.K) ? it.kbeg + g.slice_k : g.K;
         it.Ab = g.A + (long)(g.a_mod > 0 ? z % g.a_mod : z) * g.sA;
         it.Bb = g.B + (long)z * g.sB;
-        it.Cb = g.C + (long)z * g.sC;
+        it.Cb = g.C + (long)(g.c_mod > 0 ? z % g.c_mod : z) * g.sC;
+        it.r_off = (long)z * g.sR;
     };
 
     const int lane = threadIdx.x & 63;
@@ -296,7 +317,33 @@ gemm_split3_kernel(const GemmArgs g) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
     };
-    zero_acc();
+    // RES: the accumulators of a tile START as its epilogue addends (C = residual (+ residual2) + A B): the loads land
+    // straight in the accumulator registers while the first k-steps are staged, no registers of their own and nothing
+    // added to the epilogue.  Wave-uniform base + 32-bit element offsets (host: M * ldr < 2^31); rows / columns past the
+    // matrix are clamped (their sums are never stored).
+    auto init_acc = [&](const Item& it) {
+        if constexpr (!RES) { zero_acc(); return; }
+        const float* __restrict__ r1 = g.R + it.r_off;
+        const float* __restrict__ r2 = g.R2 ? g.R2 + it.r_off : nullptr;
+        const unsigned ldr = (unsigned)g.ldr;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = it.n0 + (wn * TN + j) * 32 + (lane & 31);
+            const unsigned cc_ = (unsigned)(col < g.N ? col : g.N - 1);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const long rbase = it.m0 + (wm * TM + i) * 32 + ((lane >> 5) << 2);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const long row = rbase + (r & 3) + ((r >> 2) << 3);
+                    const unsigned o = (unsigned)(row < g.M ? row : g.M - 1) * ldr + cc_;
+                    acc[i][j][r] = r1[o];
+                    if (r2 != nullptr) acc[i][j][r] += r2[o];
+                }
+            }
+        }
+    };
+    if (c_on) init_acc(cit); else zero_acc();
 
     // fragment addresses: lane l -> row (l & 31) of the 32-row block, k-block 8 (l >> 5) of the 16
     const int frag = (lane & 31) * kPitch + ((lane >> 5) << 3);
@@ -345,6 +392,61 @@ gemm_split3_kernel(const GemmArgs g) {
             }
         }
     };
+
+    // Row-contiguous epilogue (round 4): the MFMA accumulator layout gives a lane four ROWS of one column, so the direct
+    // epilogue above is 64 dword stores per thread and tile, each wave-instruction touching 2 x 128 bytes (the C stores
+    // were 29 % of the in_proj kernel, profiles/r03_gemm_ablation_v2.txt).  Here every 32 x 32 block goes through 4 KB of
+    // LDS private to the wave (the operand image is free between two tiles): 16 ds_write_b32 in accumulator order
+    // ([row][32 floats]: conflict-free), 4 ds_read_b128 by (row = lane / 8 + 8 q, four columns 4 (lane % 8)), and 4
+    // global_store_dwordx4 of 8 x 128 contiguous bytes each.  LDS operations of one wave execute in order, so the block
+    // loop needs no wait of its own beyond the data dependency; the workgroup barrier after the tile keeps the next
+    // tile's operand stores off the staging areas.  Taken when C rows are 16-byte aligned (N % 4 == 0, ldc % 4 == 0)
+    // and the tile is stored or added to plainly (no atomics).
+    auto epilogue_rows = [&](const Item& it, bool add) {
+        float bv[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bv[j] = 0.0f;
+        if (g.bias != nullptr && it.sl == 0) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = it.n0 + (wn * TN + j) * 32 + (lane & 31);
+                bv[j] = g.bias[col < g.N ? col : g.N - 1];
+            }
+            vm_wait<0>();
+#pragma unroll
+            for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(bv[j]));
+        }
+        float* stage = reinterpret_cast<float*>(smem) + wave * 1024;          // 32 x 32 floats of this wave
+        const int wr = ((lane >> 5) << 2) * 32 + (lane & 31);                 // accumulator order: row 4 (l / 32) + ..., col l % 32
+        const int rd_row = lane >> 3, rd_col = (lane & 7) << 2;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = it.n0 + (wn * TN + j) * 32 + rd_col;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) stage[wr + ((r & 3) + ((r >> 2) << 3)) * 32] = acc[i][j][r] + bv[j];
+                const long rbase = it.m0 + (wm * TM + i) * 32 + rd_row;
+                f32x4_t v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const f32x4_t*>(stage + (rd_row + 8 * q) * 32 + rd_col);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4_t* __restrict__ dst = reinterpret_cast<f32x4_t*>(it.Cb + (rbase + 8 * q) * g.ldc + col);
+                    if (col < g.N && rbase + 8 * q < g.M) {
+                        if (add) {
+                            const f32x4_t old = *dst;
+                            *dst = old + v[q];
+                        } else {
+                            *dst = v[q];
+                        }
+                    }
+                }
+            }
+        }
+    };
+    const bool rows_ok = (g.N & 3) == 0 && (g.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(g.C) & 15) == 0 && (g.sC & 3) == 0 &&
+                         !(SIGMA_GEMM_ABL & 4) && SIGMA_GEMM_ROW_EPILOGUE;
 
     while (c_on) {
 #pragma unroll
@@ -399,19 +501,21 @@ gemm_split3_kernel(const GemmArgs g) {
 #endif
             ck += kBK;
             if (ck >= cit.kend) {                      // tile (slice) complete
-                if (g.mode == 0) epilogue(cit, [](float* dst, float v) { *dst = v; });
+                if (g.mode != 2 && rows_ok) {
+                    epilogue_rows(cit, g.mode == 1);
+                    lds_barrier();                     // staging areas free before the next tile's operands are written
+                } else if (g.mode == 0) epilogue(cit, [](float* dst, float v) { *dst = v; });
                 else if (g.mode == 1) epilogue(cit, [](float* dst, float v) { *dst += v; });
                 else epilogue(cit, [](float* dst, float v) { atomicAdd(dst, v); });
-                zero_acc();
                 c_id += gridDim.x;
                 c_on = c_id < total;
-                if (c_on) { decode(c_id, cit); ck = cit.kbeg; }
+                if (c_on) { decode(c_id, cit); ck = cit.kbeg; init_acc(cit); }
             }
         }
     }
 }
 
-template <int BM, int BN, int WM, int WN, bool A_KS, bool B_KS, int P>
+template <int BM, int BN, int WM, int WN, bool A_KS, bool B_KS, int P, bool RES>
 hipError_t launch_cfg(const GemmArgs& g, int batch, hipStream_t stream) {
     const long items = (long)batch * g.ntm * g.ntn * g.slices;
     if (items <= 0 || items > 0x7fffffffL) return hipErrorInvalidValue;
@@ -422,12 +526,12 @@ hipError_t launch_cfg(const GemmArgs& g, int batch, hipStream_t stream) {
     static int per_cu = 0;                              // resident workgroups per CU of this instantiation
     if (per_cu == 0) {
         int n = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_split3_kernel<BM, BN, WM, WN, A_KS, B_KS, P>, 256, 0) != hipSuccess || n < 1) n = 2;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_split3_kernel<BM, BN, WM, WN, A_KS, B_KS, P, RES>, 256, 0) != hipSuccess || n < 1) n = 2;
         per_cu = n > 4 ? 4 : n;
     }
     long grid = 256L * per_cu;
     if (grid > items) grid = items;
-    hipLaunchKernelGGL((gemm_split3_kernel<BM, BN, WM, WN, A_KS, B_KS, P>), dim3((unsigned)grid), dim3(256), 0, stream, ga);
+    hipLaunchKernelGGL((gemm_split3_kernel<BM, BN, WM, WN, A_KS, B_KS, P, RES>), dim3((unsigned)grid), dim3(256), 0, stream, ga);
     return hipGetLastError();
 }
 
@@ -442,14 +546,24 @@ int pick_bn(int N) {
     return w96 < w128 ? 96 : 128;
 }
 
-template <bool A_KS, bool B_KS, int P>
-hipError_t launch_p(GemmArgs& g, int batch, hipStream_t stream) {
+template <bool A_KS, bool B_KS, int P, bool RES>
+hipError_t launch_r(GemmArgs& g, int batch, hipStream_t stream) {
     const int bn = pick_bn(g.N);
     g.ntm = (int)((g.M + 127) / 128);
     g.ntn = (g.N + bn - 1) / bn;
-    if (bn == 128) return launch_cfg<128, 128, 2, 2, A_KS, B_KS, P>(g, batch, stream);
-    if (bn == 96) return launch_cfg<128, 96, 4, 1, A_KS, B_KS, P>(g, batch, stream);
-    return launch_cfg<128, 64, 2, 2, A_KS, B_KS, P>(g, batch, stream);
+    if (bn == 128) return launch_cfg<128, 128, 2, 2, A_KS, B_KS, P, RES>(g, batch, stream);
+    if (bn == 96) return launch_cfg<128, 96, 4, 1, A_KS, B_KS, P, RES>(g, batch, stream);
+    return launch_cfg<128, 64, 2, 2, A_KS, B_KS, P, RES>(g, batch, stream);
+}
+
+// epilogue addends exist for the two-piece nt / nn kernels (the forward and input-gradient GEMMs of the model)
+template <bool A_KS, bool B_KS, int P>
+hipError_t launch_p(GemmArgs& g, int batch, hipStream_t stream) {
+    if constexpr (P == 2 && !(A_KS && B_KS)) {
+        if (g.R != nullptr) return launch_r<A_KS, B_KS, P, true>(g, batch, stream);
+    }
+    if (g.R != nullptr) return hipErrorInvalidValue;
+    return launch_r<A_KS, B_KS, P, false>(g, batch, stream);
 }
 
 template <bool A_KS, bool B_KS>
@@ -468,8 +582,12 @@ int fill_common(const sigma_gemm_params* p, GemmArgs& g) {
     g.A = p->A; g.B = p->Bt; g.C = p->C; g.bias = p->bias;
     g.lda = p->lda; g.ldb = p->ldb; g.ldc = p->ldc;
     g.sA = p->strideA; g.sB = p->strideB; g.sC = p->strideC;
-    g.slices = 1; g.a_mod = 0;
+    g.slices = 1; g.a_mod = 0; g.c_mod = 0;
     g.mode = p->accumulate ? 1 : 0;
+    g.R = p->residual; g.R2 = p->residual ? p->residual2 : nullptr; g.ldr = p->ldr; g.sR = p->strideR;
+    if (!p->residual && p->residual2) return SIGMA_OPS_ERR_ARG;
+    if (p->residual && (p->ldr <= 0 || p->M * p->ldr >= 0x7fffffffL)) return SIGMA_OPS_ERR_ARG;
+    if (p->c_mod < 0 || p->reserved != 0) return SIGMA_OPS_ERR_ARG;
     return SIGMA_OPS_OK;
 }
 
@@ -487,6 +605,10 @@ extern "C" int sigma_gemm_nt_split3(const sigma_gemm_params* p, void* stream) {
     if (p->K == 0) return SIGMA_OPS_ERR_ARG;
     g.slice_k = (p->K + 31) / 32 * 32;
     g.a_mod = p->a_mod;
+    if (p->c_mod > 0 && batch > p->c_mod) {          // several problems per output: summed with atomics
+        if (p->residual || p->bias) return SIGMA_OPS_ERR_ARG;
+        g.c_mod = p->c_mod; g.mode = 2;
+    } else if (p->c_mod > 0) g.c_mod = p->c_mod;
     hipError_t e = sigma::launch_any<false, false>(g, batch, p->pieces, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? SIGMA_OPS_OK : SIGMA_OPS_ERR_LAUNCH;
 }
@@ -503,6 +625,10 @@ extern "C" int sigma_gemm_nn_split3(const sigma_gemm_params* p, void* stream) {
     if (p->K == 0) return SIGMA_OPS_ERR_ARG;
     g.slice_k = (p->K + 31) / 32 * 32;
     g.a_mod = p->a_mod;
+    if (p->c_mod > 0 && batch > p->c_mod) {          // several problems per output: summed with atomics
+        if (p->residual || p->bias) return SIGMA_OPS_ERR_ARG;
+        g.c_mod = p->c_mod; g.mode = 2;
+    } else if (p->c_mod > 0) g.c_mod = p->c_mod;
     hipError_t e = sigma::launch_any<false, true>(g, batch, p->pieces, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? SIGMA_OPS_OK : SIGMA_OPS_ERR_LAUNCH;
 }
@@ -514,6 +640,7 @@ extern "C" int sigma_gemm_tn_split3(const sigma_gemm_params* p, void* stream) {
     int rc = sigma::fill_common(p, g);
     if (rc) return rc;
     if (p->N % 4 != 0 || p->K % 4 != 0) return SIGMA_OPS_ERR_ARG;
+    if (p->c_mod != 0 || p->residual) return SIGMA_OPS_ERR_ARG;      // nt / nn only
     const int batch = p->batch > 0 ? p->batch : 1;
     if (p->N == 0 || p->K == 0 || p->M == 0) return SIGMA_OPS_OK;
     g.M = p->N; g.N = p->K; g.K = (int)p->M;

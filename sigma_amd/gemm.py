@@ -37,7 +37,8 @@ from . import _capi
 MIN_DIM = 32               # smaller projections are launch / HBM bound either way
 
 
-def _params(M, N, K, A, Bt, C, bias, lda, ldb, ldc, accumulate=False, batch=1, sA=0, sB=0, sC=0, a_mod=0, pieces=2):
+def _params(M, N, K, A, Bt, C, bias, lda, ldb, ldc, accumulate=False, batch=1, sA=0, sB=0, sC=0, a_mod=0, pieces=2, c_mod=0,
+            residual=None, residual2=None, ldr=0, sR=0):
     p = _capi.GemmParams()
     p.M, p.N, p.K = int(M), int(N), int(K)
     p.A, p.Bt, p.C = A.data_ptr(), Bt.data_ptr(), C.data_ptr()
@@ -47,6 +48,10 @@ def _params(M, N, K, A, Bt, C, bias, lda, ldb, ldc, accumulate=False, batch=1, s
     p.strideA, p.strideB, p.strideC = int(sA), int(sB), int(sC)
     p.a_mod = int(a_mod)
     p.pieces = int(pieces)
+    p.c_mod = int(c_mod)
+    p.residual = residual.data_ptr() if residual is not None else None
+    p.residual2 = residual2.data_ptr() if residual2 is not None else None
+    p.ldr, p.strideR = int(ldr), int(sR)
     return p
 
 
@@ -72,9 +77,16 @@ def nt_ok(a: torch.Tensor, bt: torch.Tensor) -> bool:
     return a.shape[1] % 4 == 0 and _rows_ok(a) and _rows_ok(bt)
 
 
-def gemm_nt(a: torch.Tensor, bt: torch.Tensor, bias=None, out=None, accumulate=False, pieces: int = 2) -> torch.Tensor:
-    """out (M, N) (+)= a (M, K) @ bt (N, K)^T (+ bias).  pieces: bf16 pieces per operand element -- 2 = three MFMAs per
-    block (~4e-6 rms error), 3 = six MFMAs (~1e-6, the accuracy of an fp32 GEMM)"""
+def residual_ok(r, M: int, N: int) -> bool:
+    """an epilogue addend: fp32 (M, N) with contiguous rows, small enough for 32-bit element offsets, two pieces only"""
+    return (r is not None and r.is_cuda and r.dtype == torch.float32 and r.dim() == 2 and tuple(r.shape) == (M, N)
+            and r.stride(1) == 1 and 0 < r.stride(0) and M * r.stride(0) < 2 ** 31 - 1)
+
+
+def gemm_nt(a: torch.Tensor, bt: torch.Tensor, bias=None, out=None, accumulate=False, pieces: int = 2, residual=None) -> torch.Tensor:
+    """out (M, N) (+)= a (M, K) @ bt (N, K)^T (+ bias) (+ residual).  pieces: bf16 pieces per operand element -- 2 =
+    three MFMAs per block (~4e-6 rms error), 3 = six MFMAs (~1e-6, the accuracy of an fp32 GEMM).  ``residual``: an
+    (M, N) tensor added in the kernel (the accumulators start from it), two pieces only."""
     _check2d(a, bt)
     M, K = a.shape
     N = bt.shape[0]
@@ -84,8 +96,11 @@ def gemm_nt(a: torch.Tensor, bt: torch.Tensor, bias=None, out=None, accumulate=F
         out = torch.empty((M, N), device=a.device, dtype=torch.float32)
     elif out.stride(1) != 1 or tuple(out.shape) != (M, N):
         raise RuntimeError("gemm_nt: out must be (M, N) with contiguous rows")
+    if residual is not None and (pieces != 2 or not residual_ok(residual, M, N)):
+        raise RuntimeError("gemm_nt: residual must be an fp32 (M, N) GPU tensor with contiguous rows (two-piece kernels only)")
     if M and N:
-        _run("sigma_gemm_nt_split3", _params(M, N, K, a, bt, out, bias, a.stride(0), bt.stride(0), out.stride(0), accumulate, pieces=pieces), a.device)
+        _run("sigma_gemm_nt_split3", _params(M, N, K, a, bt, out, bias, a.stride(0), bt.stride(0), out.stride(0), accumulate, pieces=pieces,
+                                             residual=residual, ldr=residual.stride(0) if residual is not None else 0), a.device)
     return out
 
 
@@ -132,6 +147,63 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, out=None, accumulate=False, pieces
     return out
 
 
+def _check3d(name, *ts):
+    for t in ts:
+        if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 3 and t.stride(2) == 1 and t.stride(1) % 4 == 0
+                and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0):
+            raise RuntimeError(f"{name}: 3-D fp32 GPU tensors (problem, row, column) with contiguous, 16-byte aligned rows and "
+                               f"batch strides that are multiples of 4 (no fallback); got shape {tuple(t.shape)} strides {t.stride()}")
+
+
+def bgemm_ok(*ts) -> bool:
+    return all(t.is_cuda and t.dtype == torch.float32 and t.dim() == 3 and t.stride(2) == 1 and t.stride(1) % 4 == 0
+               and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0 and t.shape[2] % 4 == 0 for t in ts)
+
+
+def bgemm_nn(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, residual=None, residual2=None, pieces: int = 2) -> torch.Tensor:
+    """Stacked problems  out[z] (M, N) = a[z % Za] (M, K) @ b[z] (K, N) (+ residual[z] (+ residual2[z])):  a (Za, M, K) is
+    a weight stack shared by groups of problems (Za divides Z), b (Z, K, N) and out (Z, M, N) may be strided views of
+    larger tensors (row slices of a stacked projection).  The x_proj / dt_proj einsums of cross_selective_scan on
+    channels-first activations (vmamba.py:193-199) and their input gradients."""
+    _check3d("bgemm_nn", a, b, out)
+    Za, M, K = a.shape
+    Z, Kb, N = b.shape
+    if Kb != K or tuple(out.shape) != (Z, M, N) or Z % Za != 0 or K % 4 != 0 or N % 4 != 0:
+        raise RuntimeError(f"bgemm_nn: shapes a {tuple(a.shape)} b {tuple(b.shape)} out {tuple(out.shape)}")
+    kw = {}
+    if residual is not None:
+        _check3d("bgemm_nn residual", residual)
+        if tuple(residual.shape) != (Z, M, N) or M * residual.stride(1) >= 2 ** 31 - 1 or pieces != 2:
+            raise RuntimeError("bgemm_nn: residual must be (Z, M, N), two-piece kernels only")
+        if residual2 is not None and (tuple(residual2.shape) != (Z, M, N) or residual2.stride() != residual.stride()
+                                      or residual2.dtype != torch.float32):
+            raise RuntimeError("bgemm_nn: residual2 must have the shape and strides of residual")
+        kw = dict(residual=residual, residual2=residual2, ldr=residual.stride(1), sR=residual.stride(0))
+    elif residual2 is not None:
+        raise RuntimeError("bgemm_nn: residual2 without residual")
+    if Z and M and N:
+        _run("sigma_gemm_nn_split3", _params(M, N, K, a, b, out, None, a.stride(1), b.stride(1), out.stride(1), False, batch=Z,
+                                             sA=a.stride(0), sB=b.stride(0), sC=out.stride(0), a_mod=Za if Za != Z else 0,
+                                             pieces=pieces, **kw), a.device)
+    return out
+
+
+def bgemm_nt_sum(a: torch.Tensor, bt: torch.Tensor, out: torch.Tensor, pieces: int = 2) -> torch.Tensor:
+    """out[z % Zc] (M, N) += a[z] (M, K) @ bt[z] (N, K)^T summed over the problems that share an output (fp32 atomics):
+    out (Zc, M, N) contiguous per problem, ZERO-FILLED (or holding a value to add to) by the caller; Zc divides Z.  The
+    weight gradients of the stacked projections summed over the batch."""
+    _check3d("bgemm_nt_sum", a, bt, out)
+    Z, M, K = a.shape
+    Zb, N, Kb = bt.shape
+    Zc = out.shape[0]
+    if Zb != Z or Kb != K or tuple(out.shape[1:]) != (M, N) or Z % max(Zc, 1) != 0 or K % 4 != 0:
+        raise RuntimeError(f"bgemm_nt_sum: shapes a {tuple(a.shape)} bt {tuple(bt.shape)} out {tuple(out.shape)}")
+    if Z and M and N:
+        _run("sigma_gemm_nt_split3", _params(M, N, K, a, bt, out, None, a.stride(1), bt.stride(1), out.stride(1), True, batch=Z,
+                                             sA=a.stride(0), sB=bt.stride(0), sC=out.stride(0), c_mod=Zc, pieces=pieces), a.device)
+    return out
+
+
 def _pieces(var: str, default: str) -> int:
     """per-GEMM-kind precision knob: '2' / '3' = bf16 pieces on the MFMA kernels, 'fp32' (-> 0) = vendor fp32 GEMM"""
     v = os.environ.get(var, default)
@@ -144,14 +216,19 @@ _WGRAD = _pieces("SIGMA_GEMM_WGRAD", "2")
 
 
 class LinearSplit3Fn(torch.autograd.Function):
-    """F.linear(x2, weight, bias) for a 2-D x2 on the split-operand MFMA kernels.  2-D in, 2-D out: the output must
-    not be a view made inside the Function (in-place activations follow some linears)."""
+    """F.linear(x2, weight, bias) (+ residual) for a 2-D x2 on the split-operand MFMA kernels.  2-D in, 2-D out: the
+    output must not be a view made inside the Function (in-place activations follow some linears).  ``residual``
+    (optional, (M, out)): added inside the kernel; its gradient is the output gradient itself (no kernel)."""
 
     @staticmethod
-    def forward(ctx, x2, weight, bias):
-        y = gemm_nt(x2, weight, bias, pieces=_FWD) if _FWD else nn.functional.linear(x2, weight, bias)
+    def forward(ctx, x2, weight, bias, residual=None):
+        if residual is not None and not (_FWD == 2 and residual_ok(residual, x2.shape[0], weight.shape[0])):
+            y = (gemm_nt(x2, weight, bias, pieces=_FWD) if _FWD else nn.functional.linear(x2, weight, bias)) + residual
+        else:
+            y = gemm_nt(x2, weight, bias, pieces=_FWD, residual=residual) if _FWD else nn.functional.linear(x2, weight, bias)
         ctx.save_for_backward(x2, weight)
         ctx.has_bias = bias is not None
+        ctx.has_res = residual is not None
         return y
 
     @staticmethod
@@ -165,17 +242,24 @@ class LinearSplit3Fn(torch.autograd.Function):
             dw = gemm_tn(g2, x2, pieces=_WGRAD) if (_WGRAD and tn_ok(g2, x2)) else torch.mm(g2.t(), x2)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             db = g2.sum(0)
-        return dx, dw, db
+        return dx, dw, db, (dy if ctx.has_res and ctx.needs_input_grad[3] else None)
 
 
-def linear(x: torch.Tensor, weight: torch.Tensor, bias=None) -> torch.Tensor:
-    """nn.functional.linear on the split-operand kernels where they apply (fp32 GPU tensors, aligned rows)."""
+def linear(x: torch.Tensor, weight: torch.Tensor, bias=None, residual=None) -> torch.Tensor:
+    """nn.functional.linear (+ residual, a tensor of the output's shape) on the split-operand kernels where they apply
+    (fp32 GPU tensors, aligned rows)."""
     x2 = x.reshape(-1, x.shape[-1])
     if not (x2.is_cuda and x2.dtype == torch.float32 and weight.dtype == torch.float32 and nt_ok(x2, weight)):
         if not x2.is_cuda:
             raise RuntimeError("sigma_amd.gemm.linear: GPU tensors only (no fallback)")
-        return nn.functional.linear(x, weight, bias)
-    y2 = LinearSplit3Fn.apply(x2, weight, bias)
+        y = nn.functional.linear(x, weight, bias)
+        return y if residual is None else y + residual
+    r2 = None
+    if residual is not None:
+        if tuple(residual.shape) != (*x.shape[:-1], weight.shape[0]):
+            raise RuntimeError("sigma_amd.gemm.linear: residual must have the shape of the output")
+        r2 = residual.reshape(-1, weight.shape[0])
+    y2 = LinearSplit3Fn.apply(x2, weight, bias, r2)
     return y2.view(*x.shape[:-1], weight.shape[0])
 
 

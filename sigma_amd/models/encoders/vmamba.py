@@ -27,6 +27,7 @@ from typing import Optional
 import torch
 import torch.nn as nn
 
+from ... import gemm as _gemm
 from ...layernorm import LayerNorm
 import torch.nn.functional as F
 
@@ -235,9 +236,11 @@ class SS2D(nn.Module):
         self.out_proj = nn.Linear(self.d_inner, d_model, bias=bias)
         self.dropout = nn.Dropout(dropout) if dropout > 0.0 else nn.Identity()
 
-    def forward(self, x: torch.Tensor, branch_scale=None) -> torch.Tensor:       # x: (B, H, W, C)
+    def forward(self, x: torch.Tensor, branch_scale=None, residual=None) -> torch.Tensor:       # x: (B, H, W, C)
         """``branch_scale``: optional per-sample factor (B, 1, 1, 1) on the result -- the block's stochastic-depth mask.
-        out_proj is linear and bias-free, so the factor is applied to its input inside the gated LayerNorm pass."""
+        out_proj is linear and bias-free, so the factor is applied to its input inside the gated LayerNorm pass.
+        ``residual``: optional tensor of the output's shape that is added to the result -- the block's residual stream,
+        added inside the out_proj GEMM (its accumulators start from it) instead of in a pass of its own."""
         fold = branch_scale is not None and self.out_proj.bias is None and isinstance(self.dropout, nn.Identity)
         xz = self.in_proj(x)
         if _FUSED_SS2D and _FUSED_SPLIT and xz.is_cuda and xz.dtype == torch.float32:
@@ -262,8 +265,14 @@ class SS2D(nn.Module):
                           self.A_logs, self.Ds, self.out_norm)
             y = y * F.silu(z)
             fold = False
+        scaled_after = not (branch_scale is None or fold)
+        if (residual is not None and not scaled_after and isinstance(self.dropout, nn.Identity) and y.is_cuda
+                and y.dtype == torch.float32 and _gemm.gemm_mode() == "split3"):
+            return _gemm.linear(y, self.out_proj.weight, self.out_proj.bias, residual=residual)
         out = self.dropout(self.out_proj(y))
-        return out if (branch_scale is None or fold) else out * branch_scale
+        if scaled_after:
+            out = out * branch_scale
+        return out if residual is None else residual + out
 
 
 class PatchMerging2D(nn.Module):
@@ -304,8 +313,9 @@ class VSSBlock(nn.Module):
         self.drop_path = DropPath(drop_path)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        # x + drop_path(op(norm(x))): the per-sample mask rides inside the branch (SS2D.forward), the residual is one add
-        return x + self.op(self.norm(x), self.drop_path.draw(x))
+        # x + drop_path(op(norm(x))): the per-sample mask rides inside the branch (SS2D.forward), the residual stream is
+        # added by the branch's last GEMM
+        return self.op(self.norm(x), self.drop_path.draw(x), residual=x)
 
 
 # --------------------------------------------------------------------------- decoder block

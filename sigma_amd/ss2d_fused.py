@@ -28,12 +28,19 @@ from __future__ import annotations
 
 import torch
 
+import os as _os_early
+
+from . import gemm as _gemm
 from . import selective_scan_cuda_core as _core
 
 # kernel group g -> reference direction k.  g = 2*j + i with j = memory order (0 row-major,
 # 1 column-major) and i = flipped; reference k = j + 2*i (vmamba.py:84-89).  Self-inverse.
 _PERM = (0, 2, 1, 3)
 _REV_MASK = 0b1010
+# bf16 pieces of the x_proj / dt_proj GEMMs on the split-operand kernels (2 / 3), 0 = the vendor fp32 batched GEMM
+# (SIGMA_GEMM_XPROJ=fp32, or SIGMA_GEMM=fp32 for every GEMM of the model)
+_XPROJ_ALL = _os_early.environ.get("SIGMA_GEMM_XPROJ", "") == "all"
+_XPROJ = 0 if _gemm.gemm_mode() == "fp32" else (2 if _XPROJ_ALL else _gemm._pieces("SIGMA_GEMM_XPROJ", "2"))
 
 
 def _perm4(t: torch.Tensor) -> torch.Tensor:
@@ -347,9 +354,30 @@ class SS2DCoreFn(torch.autograd.Function):
             raise RuntimeError("SS2DCoreFn expects the 4-direction parameter stack")
         xs2 = xs2.float().contiguous()
         Wst = _perm4(x_proj_weight.float()).reshape(2, 2 * c, d)               # [order j][(flip i, row)][d]
-        p4 = torch.matmul(Wst.unsqueeze(0), xs2).view(B, 4, c, L)              # == (B, group g, R+2N, L)
-        dtw = _perm4(dt_projs_weight.float())                                  # (4, d, R)
-        delta = torch.matmul(dtw.unsqueeze(0), p4[:, :, :R])                   # (B, 4, d, L)
+        dtw = _perm4(dt_projs_weight.float()).contiguous()                     # (4, d, R)
+        # The projections on the split-operand MFMA kernels (stacked problems, weight stacks shared through a_mod, no
+        # expanded weight copies, results written straight into their slices, weight gradients summed over the batch
+        # inside the kernel) WHERE THEY BEAT the vendor fp32 batched GEMM + its helper passes -- measured per GEMM and
+        # stage in profiles/r04_xproj_bench.txt (tools/xproj_bench.py): x_proj forward everywhere, its weight gradient
+        # up to L = 1200, the rest only on the short sequences of the last stage.  SIGMA_GEMM_XPROJ=fp32 (or a reduction
+        # length that is not a multiple of 4: dt_rank 6 of the 96-channel stage) keeps the vendor GEMMs; =all takes
+        # every GEMM the kernels can (A/B runs).
+        legal = bool(_XPROJ) and L % 4 == 0 and d % 4 == 0 and c % 2 == 0
+        short = L <= 600 or _XPROJ_ALL
+        own_x = legal
+        own_dt = legal and R % 4 == 0 and short
+        ctx.own = dict(xd=legal and short, xw=legal and (L <= 1200 or _XPROJ_ALL), dd=legal and R % 4 == 0 and _XPROJ_ALL,
+                       dw=legal and R % 4 == 0 and short)
+        if own_x:
+            p4 = torch.empty((B, 4, c, L), device=xs2.device, dtype=torch.float32)
+            _gemm.bgemm_nn(Wst, xs2.view(2 * B, d, L), p4.view(2 * B, 2 * c, L), pieces=_XPROJ)
+        else:
+            p4 = torch.matmul(Wst.unsqueeze(0), xs2).view(B, 4, c, L)          # == (B, group g, R+2N, L)
+        if own_dt:
+            delta = torch.empty((B, 4, d, L), device=xs2.device, dtype=torch.float32)
+            _gemm.bgemm_nn(dtw, p4.view(4 * B, c, L)[:, :R], delta.view(4 * B, d, L), pieces=_XPROJ)
+        else:
+            delta = torch.matmul(dtw.unsqueeze(0), p4[:, :, :R])               # (B, 4, d, L)
         # A, D, bias keep the reference's direction order: the kernels map group -> parameter rows (param_swap)
         A = -torch.exp(A_logs.float())
         Dp = Ds.float()
@@ -370,6 +398,7 @@ class SS2DCoreFn(torch.autograd.Function):
     def backward(ctx, dy):
         xs2, p4, delta, A, Dp, bias, ck, Wst, dtw = ctx.saved_tensors
         B, d, H, W, c, R, N = ctx.dims
+        own = ctx.own
         L = H * W
         g2 = cross_split_nhwc(dy.float().contiguous())                         # CrossMerge^T: 2 planes, not 4
         dp4 = torch.empty_like(p4)
@@ -379,14 +408,33 @@ class SS2DCoreFn(torch.autograd.Function):
             rev_mask=_REV_MASK, u_gshift=1, dout_gshift=1, dB_out=dp4[:, :, R:R + N], dC_out=dp4[:, :, R + N:], param_swap=1,
             ckpt_pitch=ctx.pitch)
         ddelta4 = ddelta.view(B, 4, d, L)
+        # weight gradients computed by the kernels: ONE zero fill, the sum over the batch inside the kernels (atomics)
+        wg = torch.zeros(4 * d * R + 4 * c * d, device=xs2.device, dtype=torch.float32) if (own["xw"] or own["dw"]) else None
         # dt_proj: delta = dtw @ p4[:R]
-        dp4[:, :, :R] = torch.matmul(dtw.transpose(1, 2).unsqueeze(0), ddelta4)
-        d_dtw = torch.matmul(ddelta4, p4[:, :, :R].transpose(-1, -2)).sum(0)   # (4, d, R)
-        # x_proj: p = Wst @ xs2
+        if own["dd"]:
+            _gemm.bgemm_nn(dtw.transpose(1, 2).contiguous(), ddelta.view(4 * B, d, L), dp4.view(4 * B, c, L)[:, :R], pieces=_XPROJ)
+        else:
+            dp4[:, :, :R] = torch.matmul(dtw.transpose(1, 2).unsqueeze(0), ddelta4)
+        if own["dw"]:
+            d_dtw = wg[:4 * d * R].view(4, d, R)
+            _gemm.bgemm_nt_sum(ddelta.view(4 * B, d, L), p4.view(4 * B, c, L)[:, :R], d_dtw, pieces=_XPROJ)
+        else:
+            d_dtw = torch.matmul(ddelta4, p4[:, :, :R].transpose(-1, -2)).sum(0)   # (4, d, R)
+        # x_proj: p = Wst @ xs2; its input gradient joins the scan's du of both directions of an order
         dp2 = dp4.view(B, 2, 2 * c, L)
-        dxs2 = torch.matmul(Wst.transpose(1, 2).unsqueeze(0), dp2)             # (B, 2, d, L)
-        _pair_sum_add(du, dxs2, B * 2, d * L)                                  # + du of both directions of an order
-        dWst = torch.matmul(dp2, xs2.transpose(-1, -2)).sum(0)                 # (2, 2c, d)
+        if own["xd"]:
+            dxs2 = torch.empty((B, 2, d, L), device=xs2.device, dtype=torch.float32)
+            du3 = du.view(2 * B, 2, d, L)
+            _gemm.bgemm_nn(Wst.transpose(1, 2).contiguous(), dp4.view(2 * B, 2 * c, L), dxs2.view(2 * B, d, L),
+                           residual=du3[:, 0], residual2=du3[:, 1], pieces=_XPROJ)
+        else:
+            dxs2 = torch.matmul(Wst.transpose(1, 2).unsqueeze(0), dp2)         # (B, 2, d, L)
+            _pair_sum_add(du, dxs2, B * 2, d * L)                              # + du of both directions of an order
+        if own["xw"]:
+            dWst = wg[4 * d * R:].view(2, 2 * c, d)
+            _gemm.bgemm_nt_sum(dp4.view(2 * B, 2 * c, L), xs2.view(2 * B, d, L), dWst, pieces=_XPROJ)
+        else:
+            dWst = torch.matmul(dp2, xs2.transpose(-1, -2)).sum(0)             # (2, 2c, d)
         d_xproj = _perm4(dWst.view(4, c, d))                                   # the permutation is its own inverse
         d_dtw = _perm4(d_dtw)
         dA_logs = dA * A                                                       # A = -exp(A_logs); reference order already

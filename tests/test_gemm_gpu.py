@@ -150,3 +150,99 @@ def test_gemm_refuses_cpu_tensors_and_bad_shapes():
         gemm.gemm_nt(_rand(8, 6), _rand(8, 6))                       # K % 4 != 0
     with pytest.raises(RuntimeError):
         gemm.linear(torch.randn(2, 8), torch.randn(4, 8))
+
+
+# ---- round 4: stacked problems (x_proj / dt_proj of the SS2D core), epilogue addends, outputs shared by problems --------
+# (B, d, c, R, L): the four encoder stages of sigma_small at batch 2 (R = dt_rank, c = R + 2 N) and ragged ones
+CORE_SHAPES = [(2, 768, 56, 24, 1200), (2, 384, 44, 12, 4800), (1, 1536, 80, 48, 300), (2, 192, 38, 6, 1200), (3, 40, 12, 4, 36)]
+
+
+@pytest.mark.parametrize("dims", CORE_SHAPES, ids=["x".join(map(str, s)) for s in CORE_SHAPES])
+def test_stacked_projections_of_the_scan_core_against_fp64(dims):
+    """bgemm_nn with a weight stack shared by groups of problems and strided row-slice operands / outputs (p = W x,
+    delta = W_dt p[:R], their input gradients, the last one with the scan's two du as epilogue addends), bgemm_nt_sum
+    (weight gradients summed over the batch inside the kernel)."""
+    from sigma_amd import gemm
+    B, d, c, R, L = dims
+    xs = _rand(B, 2, d, L, seed=1)
+    Wst = _rand(2, 2 * c, d, seed=2, scale=0.05)
+    p4 = torch.empty(B, 4, c, L, device=DEV)
+    gemm.bgemm_nn(Wst, xs.view(2 * B, d, L), p4.view(2 * B, 2 * c, L))
+    want = torch.matmul(Wst.double().unsqueeze(0), xs.double()).view(B, 4, c, L)
+    bound = torch.matmul(Wst.double().abs().unsqueeze(0), xs.double().abs()).view(B, 4, c, L)
+    _assert_close(p4, want, bound, "x_proj")
+    if R % 4 == 0:
+        dtw = _rand(4, d, R, seed=3, scale=0.2)
+        delta = torch.full((B, 4, d, L), float("nan"), device=DEV)
+        gemm.bgemm_nn(dtw, p4.view(4 * B, c, L)[:, :R], delta.view(4 * B, d, L))
+        pr = p4[:, :, :R].double()
+        _assert_close(delta, torch.matmul(dtw.double().unsqueeze(0), pr), torch.matmul(dtw.double().abs().unsqueeze(0), pr.abs()), "dt_proj")
+        # input gradient of dt_proj written into the first R rows of every group of dp4, the others untouched
+        dd = _rand(B, 4, d, L, seed=4)
+        dp4 = torch.full((B, 4, c, L), 7.0, device=DEV)
+        gemm.bgemm_nn(dtw.transpose(1, 2).contiguous(), dd.view(4 * B, d, L), dp4.view(4 * B, c, L)[:, :R])
+        wt = dtw.double().transpose(1, 2).unsqueeze(0)
+        _assert_close(dp4[:, :, :R], torch.matmul(wt, dd.double()), torch.matmul(wt.abs(), dd.double().abs()), "dt_proj dgrad")
+        assert bool((dp4[:, :, R:] == 7.0).all())
+        # weight gradient summed over the batch
+        dW = torch.zeros(4, d, R, device=DEV)
+        gemm.bgemm_nt_sum(dd.view(4 * B, d, L), p4.view(4 * B, c, L)[:, :R], dW)
+        wantW = torch.matmul(dd.double(), pr.transpose(-1, -2)).sum(0)
+        boundW = torch.matmul(dd.double().abs(), pr.abs().transpose(-1, -2)).sum(0)
+        _assert_close(dW, wantW, boundW, "dt_proj wgrad")
+    # x_proj input gradient + the scan's du of both directions of an order, one pass
+    dp = _rand(B, 4, c, L, seed=5)
+    du = _rand(B, 4, d, L, seed=6)
+    du3 = du.view(2 * B, 2, d, L)
+    dxs = torch.empty(B, 2, d, L, device=DEV)
+    gemm.bgemm_nn(Wst.transpose(1, 2).contiguous(), dp.view(2 * B, 2 * c, L), dxs.view(2 * B, d, L), residual=du3[:, 0], residual2=du3[:, 1])
+    wt = Wst.double().transpose(1, 2).unsqueeze(0)
+    dp2 = dp.double().view(B, 2, 2 * c, L)
+    want = torch.matmul(wt, dp2) + du.double().view(B, 2, 2, d, L).sum(2)
+    bound = torch.matmul(wt.abs(), dp2.abs()) + du.double().abs().view(B, 2, 2, d, L).sum(2)
+    _assert_close(dxs, want, bound, "x_proj dgrad + du")
+    dWst = torch.zeros(2, 2 * c, d, device=DEV)
+    gemm.bgemm_nt_sum(dp.view(2 * B, 2 * c, L), xs.view(2 * B, d, L), dWst)
+    wantW = torch.matmul(dp2, xs.double().transpose(-1, -2)).sum(0)
+    boundW = torch.matmul(dp2.abs(), xs.double().abs().transpose(-1, -2)).sum(0)
+    _assert_close(dWst, wantW, boundW, "x_proj wgrad")
+
+
+@pytest.mark.parametrize("shape", [(19200, 768, 384), (4800, 384, 192), (257, 100, 72), (130, 36, 200), (5, 4, 4)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_linear_with_the_residual_added_in_the_kernel(shape):
+    """y = x W^T (+ b) + r with r entering through the accumulators: value, and the gradients of x, W, b and r"""
+    from sigma_amd import gemm
+    M, K, N = shape
+    x, w, b, r = _rand(M, K, seed=1), _rand(N, K, seed=2, scale=0.05), _rand(N, seed=3), _rand(M, N, seed=4)
+    for bias in (None, b):
+        y = gemm.gemm_nt(x, w, bias, residual=r)
+        want = x.double() @ w.double().t() + r.double() + (0 if bias is None else bias.double())
+        _assert_close(y, want, _bound(x.double(), w.double().t()) + r.double().abs() + 1.0, "nt + residual")
+    xa, wa, ba, ra = (t.clone().requires_grad_() for t in (x, w, b, r))
+    g = _rand(M, N, seed=5)
+    gemm.linear(xa.view(1, M, K), wa, ba, residual=ra.view(1, M, N)).backward(g.view(1, M, N))
+    xr, wr, br, rr = (t.double().clone().requires_grad_() for t in (x, w, b, r))
+    (torch.nn.functional.linear(xr, wr, br) + rr).backward(g.double())
+    assert torch.equal(ra.grad, g)
+    torch.testing.assert_close(ba.grad.double(), br.grad, rtol=1e-4, atol=1e-3)
+    _assert_close(xa.grad, xr.grad, _bound(g.double().abs(), w.double().abs()), "dx")
+    _assert_close(wa.grad, wr.grad, _bound(g.double().t().abs(), x.double().abs()), "dW")
+
+
+def test_stacked_gemms_refuse_what_they_cannot_take():
+    from sigma_amd import gemm
+    a, b, o = _rand(2, 8, 16), _rand(4, 16, 24), torch.empty(4, 8, 24, device=DEV)
+    gemm.bgemm_nn(a, b, o)
+    with pytest.raises(RuntimeError):
+        gemm.bgemm_nn(_rand(3, 8, 16), b, o)                       # 3 does not divide 4
+    with pytest.raises(RuntimeError):
+        gemm.bgemm_nn(a, _rand(4, 16, 22), torch.empty(4, 8, 22, device=DEV))     # N % 4
+    with pytest.raises(RuntimeError):
+        gemm.bgemm_nn(a.cpu(), b.cpu(), o.cpu())
+    with pytest.raises(RuntimeError):
+        gemm.bgemm_nn(a, b, o, residual2=o)
+    with pytest.raises(RuntimeError):
+        gemm.bgemm_nt_sum(_rand(4, 8, 16), _rand(4, 24, 16), torch.zeros(3, 8, 24, device=DEV))
+    with pytest.raises(RuntimeError):
+        gemm.gemm_nt(_rand(8, 16), _rand(24, 16), residual=_rand(8, 20))

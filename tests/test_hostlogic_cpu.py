@@ -47,9 +47,10 @@ def test_vss_and_cvss_blocks_fold_the_mask_into_the_branch(monkeypatch):
             super().__init__()
             self.lin = nn.Linear(C, C, bias=False)
 
-        def forward(self, x, branch_scale=None):
+        def forward(self, x, branch_scale=None, residual=None):
             y = self.lin(x)
-            return y if branch_scale is None else y * branch_scale
+            y = y if branch_scale is None else y * branch_scale
+            return y if residual is None else residual + y
 
     C = 8
     blk = vm.VSSBlock(hidden_dim=C, drop_path=0.5, d_state=4).train()
@@ -60,6 +61,7 @@ def test_vss_and_cvss_blocks_fold_the_mask_into_the_branch(monkeypatch):
     torch.manual_seed(2)
     mask = blk.drop_path.draw(x)
     torch.testing.assert_close(got, x + blk.op(blk.norm(x)) * mask)
+
 
     dec = vm.CVSSDecoderBlock(hidden_dim=96, drop_path=0.5, d_state=4).train()
     dec.op = Branch(96)

@@ -77,4 +77,10 @@ g)  # parity additions of this round (evaluator multi-scale, oracle-driven 480x6
     R=$PWD; ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/trace -o b8 -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline ) > $out/trace.log 2>&1; grep "^{" $out/trace.log | cut -c1-400
     tr=$(find $out/trace -name "*kernel_trace.csv" | head -1); python tools/prof_summary.py $tr --top 60 --last-ms 340 > $out/trace_summary.txt 2>&1; head -70 $out/trace_summary.txt | cut -c1-200
     ;;
+h)  # stacked x_proj / dt_proj GEMMs, residual in the out_proj GEMM: parity, then the step
+    ( time timeout 600 python -m pytest tests/test_gemm_gpu.py -q --tb=short -x ) > $out/pytest_gemm.log 2>&1; tail -4 $out/pytest_gemm.log | cut -c1-300
+    ( time timeout 1500 python -m pytest tests/test_model_gpu.py tests/test_pointwise_gpu.py -q --tb=short -x ) > $out/pytest_model.log 2>&1; tail -4 $out/pytest_model.log | cut -c1-300
+    ( timeout 600 python bench.py --no-cpu-baseline ) > $out/bench_b8.log 2>&1; grep "^{" $out/bench_b8.log | cut -c1-700
+    ( SIGMA_GEMM_XPROJ=fp32 timeout 600 python bench.py --no-cpu-baseline ) > $out/bench_b8_xproj_fp32.log 2>&1; grep "^{" $out/bench_b8_xproj_fp32.log | cut -c1-200
+    ;;
 esac
