@@ -36,7 +36,8 @@ typedef struct sigma_gemm_params {
     const float *Bt;       /* nt: (N, K), element (n, k) at Bt[n * ldb + k]: C = A * Bt^T           */
     float *C;              /* (M, N), element (m, n) at C[m * ldc + n]                              */
     const float *bias;     /* (N) added to every row, or NULL                                       */
-    int64_t lda, ldb, ldc; /* row strides in floats; lda % 4 == 0, ldb % 4 == 0                     */
+    int64_t lda, ldb, ldc; /* row strides in floats; lda % 4 == 0, ldb % 4 == 0, both <= 2^22 (32-bit tile
+                              offsets inside the kernels)                                           */
     int32_t accumulate;    /* 1: C += A * Bt^T (+ bias), 0: C = ...                                 */
     int32_t batch;         /* >= 1: `batch` independent problems, operand b at base + b * stride    */
     int64_t strideA, strideB, strideC;   /* batch strides in floats (0: shared by every problem)    */
@@ -78,6 +79,14 @@ int sigma_gemm_nn_split3(const sigma_gemm_params *params, void *stream);
  *       into C, which the CALLER zero-fills unless accumulate = 1 (run-to-run differences at rounding level,
  *       like the reference's atomicAdd gradients, selective_scan_bwd_kernel.cuh:214-231).                   */
 int sigma_gemm_tn_split3(const sigma_gemm_params *params, void *stream);
+
+/*   sigma_gemm_selftest
+ *       runs the three forms on a small ragged problem whose products are exact in fp32 and compares with host
+ *       arithmetic (the operand loads of the kernels are hand-counted inline assembly: a toolchain that schedules them
+ *       differently fails here instead of in a model).  Allocates and frees its own buffers, synchronises `stream`.
+ *       0 = pass, 1 / 2 / 3 = nt / nn / tn differ, negative = a HIP call failed.  sigma_amd/gemm.py calls it once per
+ *       process and device before the first GEMM.                                                              */
+int sigma_gemm_selftest(void *stream);
 
 #ifdef __cplusplus
 }

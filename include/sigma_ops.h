@@ -183,6 +183,10 @@ typedef struct sigma_layernorm_params {
      * on load.  The out_proj that follows is linear and bias-free, so scaling its input scales the branch.  NULL = 1. */
     const float *row_scale;
     int64_t rows_per_scale;
+    /* ABI 8: optional addend of dx, (rows, C) contiguous, 16-byte aligned (may be dx itself): the gradient that reached x
+     * on the path AROUND the LayerNorm -- the residual stream of a block, x + op(norm(x)) (vmamba.py:1716-1722) --
+     * joined here instead of in an add pass of its own.  Backward only; NULL = none. */
+    const float *dx_add;
 } sigma_layernorm_params;
 
 int sigma_layernorm_fwd(const sigma_layernorm_params *params, void *stream);

@@ -109,6 +109,7 @@ class LayerNormParams(ctypes.Structure):
         ("gate", ctypes.c_void_p), ("gate_row_stride", ctypes.c_int64), ("dgate", ctypes.c_void_p),
         ("dgate_row_stride", ctypes.c_int64),
         ("row_scale", ctypes.c_void_p), ("rows_per_scale", ctypes.c_int64),
+        ("dx_add", ctypes.c_void_p),
     ]
 
 
@@ -139,6 +140,7 @@ SIGMA_CE_BLOCKS = 1024      # include/sigma_ops.h
 
 # every symbol include/sigma_gemm.h declares
 GEMM_SYMBOLS = ("sigma_gemm_nt_split3", "sigma_gemm_nn_split3", "sigma_gemm_tn_split3")
+GEMM_AUX_SYMBOLS = ("sigma_gemm_selftest",)
 
 # every symbol include/sigma_ops.h declares
 OPS_SYMBOLS = ("sigma_dwconv3x3_silu_fwd", "sigma_dwconv3x3_silu_bwd", "sigma_cross_merge_nhwc", "sigma_cross_split_nhwc",
@@ -233,6 +235,8 @@ def load() -> ctypes.CDLL:
         fn = getattr(lib, name)
         fn.argtypes = [P(GemmParams), ctypes.c_void_p]
         fn.restype = ctypes.c_int
+    lib.sigma_gemm_selftest.argtypes = [ctypes.c_void_p]
+    lib.sigma_gemm_selftest.restype = ctypes.c_int
     if lib.sigma_scan_abi_version() != SIGMA_SCAN_ABI_VERSION:
         raise SigmaHipUnavailable(
             f"ABI mismatch: library {lib.sigma_scan_abi_version()} vs binding {SIGMA_SCAN_ABI_VERSION}; rebuild")

@@ -578,6 +578,8 @@ int fill_common(const sigma_gemm_params* p, GemmArgs& g) {
     if (p->M < 0 || p->N < 0 || p->K < 0 || p->batch < 0) return SIGMA_OPS_ERR_ARG;
     if (p->pieces != 0 && p->pieces != 2 && p->pieces != 3) return SIGMA_OPS_ERR_ARG;
     if (!aligned16(p->A) || !aligned16(p->Bt) || p->lda % 4 != 0 || p->ldb % 4 != 0) return SIGMA_OPS_ERR_ARG;
+    // a tile is addressed with 32-bit byte offsets from a wave-uniform base: 127 rows x ld x 4 bytes must fit
+    if (p->lda <= 0 || p->ldb <= 0 || p->lda > (1L << 22) || p->ldb > (1L << 22)) return SIGMA_OPS_ERR_ARG;
     if (p->batch > 1 && (p->strideA % 4 != 0 || p->strideB % 4 != 0)) return SIGMA_OPS_ERR_ARG;
     g.A = p->A; g.B = p->Bt; g.C = p->C; g.bias = p->bias;
     g.lda = p->lda; g.ldb = p->ldb; g.ldc = p->ldc;
@@ -658,4 +660,63 @@ extern "C" int sigma_gemm_tn_split3(const sigma_gemm_params* p, void* stream) {
     if (g.slices > 1) g.mode = 2;                     // caller zero-filled C (or accumulates)
     hipError_t e = sigma::launch_any<true, true>(g, batch, p->pieces, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? SIGMA_OPS_OK : SIGMA_OPS_ERR_LAUNCH;
+}
+
+// Self test: the three kernel forms on operands whose products and sums are exact in fp32 (integers of small magnitude:
+// the bf16 split is then exact too), compared with host arithmetic; ragged sizes, so that partial tiles, the partial
+// k-step and the row-contiguous epilogue all run.  Synchronises `stream`.  0 = pass; 1..3 = nt / nn / tn differ;
+// negative = a HIP call failed.
+extern "C" int sigma_gemm_selftest(void* stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int M = 200, N = 72, K = 44;
+    const size_t nA = (size_t)M * K, nB = (size_t)N * K, nC = (size_t)M * N, nG = (size_t)M * N, nW = (size_t)N * K, nX = (size_t)M * K;
+    float *hA = new float[nA], *hB = new float[nB], *hG = new float[nG], *hC = new float[nC], *hX = new float[nX], *hW = new float[nW];
+    unsigned st = 12345u;
+    auto rnd = [&]() { st = st * 1664525u + 1013904223u; return (float)((int)((st >> 16) % 17) - 8); };
+    for (size_t i = 0; i < nA; ++i) hA[i] = rnd();
+    for (size_t i = 0; i < nB; ++i) hB[i] = rnd();
+    for (size_t i = 0; i < nG; ++i) hG[i] = rnd();
+    float *dA = nullptr, *dB = nullptr, *dG = nullptr, *dC = nullptr, *dX = nullptr, *dW = nullptr;
+    int rc = 0;
+    auto ok = [&](hipError_t e) { if (e != hipSuccess && rc == 0) rc = -1; return e == hipSuccess; };
+    if (ok(hipMalloc(&dA, nA * 4)) && ok(hipMalloc(&dB, nB * 4)) && ok(hipMalloc(&dG, nG * 4)) && ok(hipMalloc(&dC, nC * 4)) &&
+        ok(hipMalloc(&dX, nX * 4)) && ok(hipMalloc(&dW, nW * 4)) &&
+        ok(hipMemcpyAsync(dA, hA, nA * 4, hipMemcpyHostToDevice, s)) && ok(hipMemcpyAsync(dB, hB, nB * 4, hipMemcpyHostToDevice, s)) &&
+        ok(hipMemcpyAsync(dG, hG, nG * 4, hipMemcpyHostToDevice, s)) && ok(hipMemsetAsync(dW, 0, nW * 4, s))) {
+        sigma_gemm_params p{};
+        p.batch = 1; p.pieces = 2;
+        // nt: C = A B^T
+        p.M = M; p.N = N; p.K = K; p.A = dA; p.Bt = dB; p.C = dC; p.lda = K; p.ldb = K; p.ldc = N;
+        if (sigma_gemm_nt_split3(&p, stream) != 0) rc = -2;
+        // nn: X = G B   (G (M, N), B (N, K) row-major)
+        p.M = M; p.N = K; p.K = N; p.A = dG; p.Bt = dB; p.C = dX; p.lda = N; p.ldb = K; p.ldc = K;
+        if (rc == 0 && sigma_gemm_nn_split3(&p, stream) != 0) rc = -2;
+        // tn: W = G^T A  (reduction over the M rows)
+        p.M = M; p.N = N; p.K = K; p.A = dG; p.Bt = dA; p.C = dW; p.lda = N; p.ldb = K; p.ldc = K; p.accumulate = 1;
+        if (rc == 0 && sigma_gemm_tn_split3(&p, stream) != 0) rc = -2;
+        if (rc == 0 && ok(hipMemcpyAsync(hC, dC, nC * 4, hipMemcpyDeviceToHost, s)) && ok(hipMemcpyAsync(hX, dX, nX * 4, hipMemcpyDeviceToHost, s)) &&
+            ok(hipMemcpyAsync(hW, dW, nW * 4, hipMemcpyDeviceToHost, s)) && ok(hipStreamSynchronize(s))) {
+            for (int m = 0; m < M && rc == 0; ++m)
+                for (int n = 0; n < N; ++n) {
+                    float acc = 0.0f;
+                    for (int k = 0; k < K; ++k) acc += hA[(size_t)m * K + k] * hB[(size_t)n * K + k];
+                    if (hC[(size_t)m * N + n] != acc) { rc = 1; break; }
+                }
+            for (int m = 0; m < M && rc == 0; ++m)
+                for (int k = 0; k < K; ++k) {
+                    float acc = 0.0f;
+                    for (int n = 0; n < N; ++n) acc += hG[(size_t)m * N + n] * hB[(size_t)n * K + k];
+                    if (hX[(size_t)m * K + k] != acc) { rc = 2; break; }
+                }
+            for (int n = 0; n < N && rc == 0; ++n)
+                for (int k = 0; k < K; ++k) {
+                    float acc = 0.0f;
+                    for (int m = 0; m < M; ++m) acc += hG[(size_t)m * N + n] * hA[(size_t)m * K + k];
+                    if (hW[(size_t)n * K + k] != acc) { rc = 3; break; }
+                }
+        }
+    }
+    (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dG); (void)hipFree(dC); (void)hipFree(dX); (void)hipFree(dW);
+    delete[] hA; delete[] hB; delete[] hG; delete[] hC; delete[] hX; delete[] hW;
+    return rc;
 }

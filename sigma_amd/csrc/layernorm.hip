@@ -32,6 +32,7 @@ struct LnArgs {
     float* y; float* mean; float* rstd; float* dx; float* ws;   // ws: [nwaves][2][C]
     const float* z; float* dz; long z_stride, dz_stride;          // optional SiLU gate: y = LN(x) * silu(z)
     const float* rsc; long rows_per_scale;                        // optional per-sample output factor (stochastic depth)
+    const float* dx_add;                                          // optional addend of dx (the gradient of the residual stream)
     long M; int C; float eps;
 };
 
@@ -212,6 +213,7 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const LnArgs a) {
         }
         const float m1 = wave_allsum(s1) * inv, m2 = wave_allsum(s2) * inv;
         float* __restrict__ dr = a.dx + r * C;
+        const float* __restrict__ ar = a.dx_add ? a.dx_add + r * C : nullptr;
 #pragma unroll
         for (int j = 0; j < NV; ++j) {
             const int c = lane * 4 + 256 * j;
@@ -221,6 +223,10 @@ __global__ void __launch_bounds__(256) ln_bwd_kernel(const LnArgs a) {
                 o.y = rs * (t[j].y - m1 - xh[j].y * m2);
                 o.z = rs * (t[j].z - m1 - xh[j].z * m2);
                 o.w = rs * (t[j].w - m1 - xh[j].w * m2);
+                if (ar) {                                       // + the gradient that reached x past the LayerNorm
+                    const float4 e = *reinterpret_cast<const float4*>(ar + c);
+                    o.x += e.x; o.y += e.y; o.z += e.z; o.w += e.w;
+                }
                 *reinterpret_cast<float4*>(dr + c) = o;
             }
         }
@@ -390,6 +396,8 @@ int sigma_layernorm_bwd(const sigma_layernorm_params* p, void* stream) {
         a.ws = p->workspace; a.z = p->gate; a.z_stride = p->gate_row_stride; a.dz = p->dgate;
         a.dz_stride = p->dgate_row_stride > 0 ? p->dgate_row_stride : p->channels;
         a.rsc = p->row_scale; a.rows_per_scale = p->rows_per_scale;
+        a.dx_add = p->dx_add;
+        if (p->dx_add && (reinterpret_cast<uintptr_t>(p->dx_add) & 15)) return SIGMA_OPS_ERR_ARG;
         if (p->row_scale && p->rows_per_scale <= 0) return SIGMA_OPS_ERR_ARG;
         if (p->gate && (!p->dgate || p->gate_row_stride % 4 != 0 || p->gate_row_stride < p->channels || a.dz_stride % 4 != 0 ||
                         a.dz_stride < p->channels))

@@ -55,7 +55,26 @@ def _params(M, N, K, A, Bt, C, bias, lda, ldb, ldc, accumulate=False, batch=1, s
     return p
 
 
+_SELFTESTED = set()
+
+
+def _selftest(dev) -> None:
+    """Once per process and device: sigma_gemm_selftest (csrc/gemm_split.hip) runs the three kernel forms on operands
+    whose products are exact in fp32 and compares with host arithmetic -- the operand loads are hand-counted inline
+    assembly, so a toolchain that schedules them differently must fail HERE, loudly."""
+    key = (dev.index if dev.index is not None else torch.cuda.current_device())
+    if key in _SELFTESTED:
+        return
+    with torch.cuda.device(dev):
+        rc = _capi.load().sigma_gemm_selftest(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    if rc != 0:
+        raise RuntimeError(f"sigma_gemm_selftest failed on {dev} (code {rc}): the split-operand GEMM kernels of this build do not "
+                           f"compute A B^T exactly on an exactly representable problem; rebuild libsigma_hip.so with the supported ROCm")
+    _SELFTESTED.add(key)
+
+
 def _run(name, p, dev):
+    _selftest(dev)
     with torch.cuda.device(dev):
         rc = getattr(_capi.load(), name)(ctypes.byref(p), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     if rc != 0:
@@ -68,9 +87,21 @@ def _check2d(*ts):
             raise RuntimeError("sigma_amd.gemm: 2-D fp32 GPU tensors only (no fallback)")
 
 
+_MAX_LD = 1 << 22          # the kernels address a tile with 32-bit byte offsets: 127 rows x ld x 4 bytes < 2^32 (capi: same bound)
+
+
 def _rows_ok(t: torch.Tensor) -> bool:
-    """last dimension contiguous, 16-byte aligned rows"""
-    return t.stride(1) == 1 and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0
+    """last dimension contiguous, 16-byte aligned rows, row stride inside the kernels' 32-bit tile offsets"""
+    return t.stride(1) == 1 and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0 and 0 < t.stride(0) <= _MAX_LD
+
+
+def _check_aux(name, bias, out, N, dev):
+    """bias / out are read and written as raw fp32 by the kernels: refuse anything else"""
+    if bias is not None and not (bias.is_cuda and bias.device == dev and bias.dtype == torch.float32 and bias.dim() == 1
+                                 and bias.numel() == N and bias.is_contiguous()):
+        raise RuntimeError(f"{name}: bias must be a contiguous fp32 vector of {N} elements on {dev}")
+    if out is not None and not (out.is_cuda and out.device == dev and out.dtype == torch.float32 and out.dim() == 2):
+        raise RuntimeError(f"{name}: out must be a 2-D fp32 tensor on {dev}")
 
 
 def nt_ok(a: torch.Tensor, bt: torch.Tensor) -> bool:
@@ -92,6 +123,7 @@ def gemm_nt(a: torch.Tensor, bt: torch.Tensor, bias=None, out=None, accumulate=F
     N = bt.shape[0]
     if bt.shape[1] != K or not nt_ok(a, bt):
         raise RuntimeError("gemm_nt: operands must be (M, K) and (N, K) with K % 4 == 0 and 16-byte aligned rows")
+    _check_aux("gemm_nt", bias, out, N, a.device)
     if out is None:
         out = torch.empty((M, N), device=a.device, dtype=torch.float32)
     elif out.stride(1) != 1 or tuple(out.shape) != (M, N):
@@ -115,6 +147,7 @@ def gemm_nn(a: torch.Tensor, b: torch.Tensor, out=None, accumulate=False, pieces
     N = b.shape[1]
     if b.shape[0] != K or not nn_ok(a, b):
         raise RuntimeError("gemm_nn: operands must be (M, K) and (K, N) with K % 4 == 0, N % 4 == 0 and 16-byte aligned rows")
+    _check_aux("gemm_nn", None, out, N, a.device)
     if out is None:
         out = torch.empty((M, N), device=a.device, dtype=torch.float32)
     elif out.stride(1) != 1 or tuple(out.shape) != (M, N):
@@ -135,6 +168,11 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, out=None, accumulate=False, pieces
     K = b.shape[1]
     if b.shape[0] != M or not tn_ok(a, b):
         raise RuntimeError("gemm_tn: operands must be (M, N) and (M, K) with N % 4 == 0, K % 4 == 0 and 16-byte aligned rows")
+    _check_aux("gemm_tn", None, out, K, a.device)
+    if M == 0:                                               # no tokens: the gradient is zero (or what `out` holds)
+        if out is None:
+            return torch.zeros((N, K), device=a.device, dtype=torch.float32)
+        return out if accumulate else out.zero_()
     if out is None:
         out = torch.zeros((N, K), device=a.device, dtype=torch.float32)      # slices are summed with atomics
     elif out.stride(1) != 1 or tuple(out.shape) != (N, K):

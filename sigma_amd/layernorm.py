@@ -13,6 +13,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _capi
+from ._handoff import offer_xz_grad_buffer
 
 
 def _gate_view(z: torch.Tensor, C: int):
@@ -78,38 +79,68 @@ class LayerNormFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        lib = _capi.load()
-        xc, weight, mean, rstd, bias, zk, rsc = ctx.saved_tensors
-        C = xc.shape[-1]
-        rows = xc.numel() // C
-        dy = dy.contiguous()
-        dx = torch.empty_like(xc)
-        dgamma = torch.empty_like(weight)
-        dbeta = torch.empty_like(weight) if ctx.has_bias else None
-        nrows = int(lib.sigma_layernorm_bwd_partial_rows(rows, C))
-        ws = torch.empty(max(nrows, 1) * 2 * C, device=xc.device, dtype=torch.float32)
-        p = _capi.LayerNormParams()
-        p.rows, p.channels, p.eps = rows, C, ctx.eps
-        p.x, p.gamma, p.mean, p.rstd = xc.data_ptr(), weight.data_ptr(), mean.data_ptr(), rstd.data_ptr()
-        p.dy, p.dx, p.dgamma, p.workspace = dy.data_ptr(), dx.data_ptr(), dgamma.data_ptr(), ws.data_ptr()
-        p.dbeta = dbeta.data_ptr() if dbeta is not None else None
-        if ctx.scaled:
-            p.row_scale, p.rows_per_scale = rsc.data_ptr(), rows // rsc.numel()
-        dz = None
-        if ctx.gated:
-            if ctx.gate_half:
-                full = torch.empty(*ctx.gate_shape[:-1], 2 * C, device=xc.device, dtype=torch.float32)
-                full._sigma_xz_grad = True        # SplitXZFn.backward completes THIS buffer in place, and no other
-                dz = full[..., C:]
-                p.dgate_row_stride = 2 * C
-            else:
-                dz = torch.empty(ctx.gate_shape, device=xc.device, dtype=torch.float32)
-            p.beta = bias.data_ptr() if ctx.has_bias else None
-            p.gate, p.gate_row_stride, p.dgate = zk.data_ptr(), ctx.zstride, dz.data_ptr()
-        with torch.cuda.device(xc.device):
-            _capi.check(lib.sigma_layernorm_bwd(ctypes.byref(p), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
-                        "layernorm_bwd")
-        return dx, dgamma, dbeta, None, dz, None
+        return _ln_backward(ctx, dy, None)
+
+
+def _ln_backward(ctx, dy, dx_add):
+    """sigma_layernorm_bwd for a context saved by LayerNormFn.forward; ``dx_add``: gradient that reached x around the
+    LayerNorm, added to dx inside the kernel"""
+    lib = _capi.load()
+    xc, weight, mean, rstd, bias, zk, rsc = ctx.saved_tensors
+    C = xc.shape[-1]
+    rows = xc.numel() // C
+    dy = dy.contiguous()
+    dx = torch.empty_like(xc)
+    dgamma = torch.empty_like(weight)
+    dbeta = torch.empty_like(weight) if ctx.has_bias else None
+    nrows = int(lib.sigma_layernorm_bwd_partial_rows(rows, C))
+    ws = torch.empty(max(nrows, 1) * 2 * C, device=xc.device, dtype=torch.float32)
+    p = _capi.LayerNormParams()
+    p.rows, p.channels, p.eps = rows, C, ctx.eps
+    p.x, p.gamma, p.mean, p.rstd = xc.data_ptr(), weight.data_ptr(), mean.data_ptr(), rstd.data_ptr()
+    p.dy, p.dx, p.dgamma, p.workspace = dy.data_ptr(), dx.data_ptr(), dgamma.data_ptr(), ws.data_ptr()
+    p.dbeta = dbeta.data_ptr() if dbeta is not None else None
+    if ctx.scaled:
+        p.row_scale, p.rows_per_scale = rsc.data_ptr(), rows // rsc.numel()
+    if dx_add is not None:
+        if tuple(dx_add.shape) != tuple(xc.shape) or dx_add.dtype != torch.float32:
+            raise RuntimeError("layernorm backward: the residual gradient must have the shape of x")
+        dx_add = dx_add.contiguous()
+        if dx_add.data_ptr() % 16:
+            dx_add = dx_add.clone()
+        p.dx_add = dx_add.data_ptr()
+    dz = None
+    if ctx.gated:
+        if ctx.gate_half:
+            full = torch.empty(*ctx.gate_shape[:-1], 2 * C, device=xc.device, dtype=torch.float32)
+            offer_xz_grad_buffer(full, C)     # SplitXZFn.backward completes THIS buffer in place (_handoff.py)
+            dz = full[..., C:]
+            p.dgate_row_stride = 2 * C
+        else:
+            dz = torch.empty(ctx.gate_shape, device=xc.device, dtype=torch.float32)
+        p.beta = bias.data_ptr() if ctx.has_bias else None
+        p.gate, p.gate_row_stride, p.dgate = zk.data_ptr(), ctx.zstride, dz.data_ptr()
+    with torch.cuda.device(xc.device):
+        _capi.check(lib.sigma_layernorm_bwd(ctypes.byref(p), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                    "layernorm_bwd")
+    return dx, dgamma, dbeta, None, dz, None
+
+
+class LayerNormResidualFn(torch.autograd.Function):
+    """(LayerNorm(x), x): the block input is handed through, so that the gradient of the residual stream
+    (x + op(norm(x)), vmamba.py:1716-1722) reaches THIS node together with the LayerNorm's and the two are joined
+    inside the backward kernel (dx_add) instead of by an add pass of the autograd engine."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        y = LayerNormFn.forward(ctx, x, weight, bias, eps)
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dpass):
+        if dy is None:                                      # the normalised branch was not used
+            return dpass, None, None, None
+        return _ln_backward(ctx, dy, dpass)[:4]
 
 
 def _aligned16(*tensors) -> bool:
@@ -129,6 +160,16 @@ class LayerNorm(nn.LayerNorm):
                 and _aligned16(self.weight, self.bias) and (not x.is_contiguous() or x.data_ptr() % 16 == 0)):
             return LayerNormFn.apply(x, self.weight, self.bias, self.eps)
         return F.layer_norm(x, self.normalized_shape, self.weight, self.bias, self.eps)
+
+    def forward_with_pass(self, x: torch.Tensor):
+        """(LayerNorm(x), x) for a residual block: use the second result as the residual operand and its gradient is
+        added to the LayerNorm's inside the backward kernel (one pass less per block)."""
+        C = x.shape[-1] if x.dim() > 0 else 0
+        if (x.is_cuda and x.dtype == torch.float32 and self.elementwise_affine and len(self.normalized_shape) == 1
+                and C % 4 == 0 and 0 < C <= 2048 and x.numel() > 0 and x.requires_grad and torch.is_grad_enabled()
+                and _aligned16(self.weight, self.bias) and x.is_contiguous() and x.data_ptr() % 16 == 0):
+            return LayerNormResidualFn.apply(x, self.weight, self.bias, self.eps)
+        return self.forward(x), x
 
     def forward_gated(self, x: torch.Tensor, z: torch.Tensor, row_scale=None) -> torch.Tensor:
         """LayerNorm(x) * silu(z) in one pass (SS2D.forward, vmamba.py:1077); z may be the strided

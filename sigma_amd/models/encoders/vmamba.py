@@ -315,7 +315,11 @@ class VSSBlock(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         # x + drop_path(op(norm(x))): the per-sample mask rides inside the branch (SS2D.forward), the residual stream is
         # added by the branch's last GEMM
-        return self.op(self.norm(x), self.drop_path.draw(x), residual=x)
+        if isinstance(self.norm, LayerNorm):
+            y, x = self.norm.forward_with_pass(x)       # the residual gradient joins the LayerNorm backward (one pass less)
+        else:
+            y = self.norm(x)
+        return self.op(y, self.drop_path.draw(x), residual=x)
 
 
 # --------------------------------------------------------------------------- decoder block

@@ -130,7 +130,10 @@ class SoftmaxCEFn(torch.autograd.Function):
 
 def cross_entropy(criterion, logits: torch.Tensor, label: torch.Tensor):
     """criterion(logits, label) for a plain mean-reduced nn.CrossEntropyLoss on channels-last logits -- logits is the
-    (B, classes, H, W) VIEW of a contiguous (B, H, W, classes) tensor -- or None when this path does not apply."""
+    (B, classes, H, W) VIEW of a contiguous (B, H, W, classes) tensor -- or None when this path does not apply.
+    Labels outside [0, classes) that are not ``ignore_index`` are treated as ignored (csrc/pointwise.hip), where
+    torch's kernel device-asserts: the reference's datasets map every unlabeled pixel to 255 = ignore_index
+    (dataloader/RGBXDataset.py), so such labels do not occur on this path."""
     if not (type(criterion) is nn.CrossEntropyLoss and criterion.reduction == "mean" and criterion.weight is None
             and getattr(criterion, "label_smoothing", 0.0) == 0.0):
         return None

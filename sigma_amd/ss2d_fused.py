@@ -31,6 +31,7 @@ import torch
 import os as _os_early
 
 from . import gemm as _gemm
+from ._handoff import claim_xz_grad_buffer
 from . import selective_scan_cuda_core as _core
 
 # kernel group g -> reference direction k.  g = 2*j + i with j = memory order (0 row-major,
@@ -219,13 +220,8 @@ class SplitXZFn(torch.autograd.Function):
     def backward(ctx, dx, dz):
         B, H, W, d = ctx.dims
         L = H * W
-        base = dz._base if dz is not None else None
-        if (base is not None and getattr(base, "_sigma_xz_grad", False) and tuple(base.shape) == (B, H, W, 2 * d)
-                and base.is_contiguous() and base.dtype == dx.dtype
-                and tuple(dz.shape) == (B, H, W, d) and dz.data_ptr() == base.data_ptr() + 4 * d and dz.stride(-1) == 1
-                and dz.stride(-2) == 2 * d):
-            dxz = base                    # the gated LayerNorm's backward wrote dz into the z half already (layernorm.py)
-        else:
+        dxz = claim_xz_grad_buffer(dz, (B, H, W, 2 * d)) if (dz is not None and dz.dtype == dx.dtype) else None
+        if dxz is None:                   # else: the gated LayerNorm's backward wrote dz into the z half already (layernorm.py)
             dxz = torch.empty(B, H, W, 2 * d, device=dx.device, dtype=dx.dtype)
             if dz is None:
                 dxz[..., d:].zero_()

@@ -148,3 +148,21 @@ def test_gemm_and_gate_wrappers_refuse_cpu_tensors():
         gemm.linear(torch.randn(2, 3, 16), b)
     with pytest.raises(RuntimeError):
         channel_gate(torch.randn(1, 8, 3, 3), torch.randn(2, 8, 1, 1), torch.randn(8, 2, 1, 1))
+
+
+def test_gradient_buffer_hand_off_matches_only_the_registered_half():
+    """sigma_amd/_handoff.py: claimed once, by the z half itself; clones, other geometries and stale entries do not match"""
+    from sigma_amd import _handoff as h
+    h._XZ_GRAD_BUFFERS.clear()
+    full = torch.zeros(2, 3, 4, 8)
+    h.offer_xz_grad_buffer(full, 4)
+    dz = full[..., 4:]
+    assert h.claim_xz_grad_buffer(dz.clone(), (2, 3, 4, 8)) is None          # another tensor: no match, entry kept
+    assert h.claim_xz_grad_buffer(dz, (2, 3, 4, 8)) is full
+    assert h.claim_xz_grad_buffer(dz, (2, 3, 4, 8)) is None                  # claimed once
+    h.offer_xz_grad_buffer(full, 4)
+    assert h.claim_xz_grad_buffer(dz, (2, 3, 2, 16)) is None                 # geometry mismatch consumes and refuses
+    for _ in range(3 * h._XZ_GRAD_KEEP):
+        h.offer_xz_grad_buffer(torch.zeros(1, 1, 2, 8), 4)
+    assert len(h._XZ_GRAD_BUFFERS) <= h._XZ_GRAD_KEEP
+    assert h.claim_xz_grad_buffer(None, (1, 1, 2, 8)) is None

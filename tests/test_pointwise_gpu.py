@@ -180,3 +180,84 @@ def test_pair_sum_add_matches_torch(n_outer, inner):
     want = acc + src[:, 0] + src[:, 1]
     _pair_sum_add(src, acc, n_outer, inner)
     torch.testing.assert_close(acc, want, rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("shape", [(4, 30, 40, 384), (2, 7, 9, 96), (3, 5, 1, 2048), (1, 1, 1, 4)], ids=lambda s: "x".join(map(str, s)))
+def test_layernorm_that_hands_its_input_through_joins_the_residual_gradient(shape):
+    """LayerNorm.forward_with_pass (round 4): (LN(x), x) with d x = LN backward + the gradient of the handed-through
+    tensor, added inside the kernel (sigma_layernorm_params.dx_add) -- against torch's two nodes and its add"""
+    from sigma_amd.layernorm import LayerNorm
+    C = shape[-1]
+    g = torch.Generator().manual_seed(C)
+    ln = LayerNorm(C).cuda()
+    with torch.no_grad():
+        ln.weight.copy_(torch.randn(C, generator=g))
+        ln.bias.copy_(torch.randn(C, generator=g))
+    x = torch.randn(shape, generator=g).cuda()
+    gy, gp = torch.randn(shape, generator=g).cuda(), torch.randn(shape, generator=g).cuda()
+    a = x.clone().requires_grad_()
+    y, p = ln.forward_with_pass(a)
+    assert p.data_ptr() == a.data_ptr()
+    (y * gy + p * gp).sum().backward()
+    b = x.clone().requires_grad_()
+    ln2 = torch.nn.LayerNorm(C).cuda()
+    ln2.load_state_dict(ln.state_dict())
+    (ln2(b) * gy + b * gp).sum().backward()
+    torch.testing.assert_close(y, ln2(b), rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(a.grad, b.grad, rtol=2e-5, atol=3e-5 * float(b.grad.abs().max()))
+    torch.testing.assert_close(ln.weight.grad, ln2.weight.grad, rtol=1e-4, atol=1e-4 * float(ln2.weight.grad.abs().max()))
+    torch.testing.assert_close(ln.bias.grad, ln2.bias.grad, rtol=1e-4, atol=1e-4 * float(ln2.bias.grad.abs().max()))
+    # only the handed-through tensor used / only the normalised one used
+    c = x.clone().requires_grad_()
+    _, p = ln.forward_with_pass(c)
+    (p * gp).sum().backward()
+    torch.testing.assert_close(c.grad, gp)
+    d = x.clone().requires_grad_()
+    y, _ = ln.forward_with_pass(d)
+    (y * gy).sum().backward()
+    e = x.clone().requires_grad_()
+    (ln2(e) * gy).sum().backward()
+    torch.testing.assert_close(d.grad, e.grad, rtol=2e-5, atol=3e-5 * float(e.grad.abs().max()))
+    with torch.no_grad():                                    # no graph: the plain path, the tensor itself
+        y, p = ln.forward_with_pass(x)
+        assert p is x
+
+
+@pytest.mark.parametrize("mode", ["single", "second_consumer", "hook"])
+def test_in_proj_gradient_buffer_hand_off_takes_the_copying_path_when_z_has_company(mode):
+    """split_xz + gated LayerNorm: the LayerNorm backward writes dz into the z half of one (B, H, W, 2d) buffer that
+    SplitXZFn.backward completes in place (sigma_amd/_handoff.py).  With a second consumer of z, or a hook on z, the
+    gradient reaching SplitXZFn is another tensor: the hand-off must not match and the result must still be right."""
+    import torch.nn.functional as F
+    from sigma_amd.layernorm import LayerNorm
+    from sigma_amd.ss2d_fused import split_xz
+    from sigma_amd import _handoff
+    B, H, W, d = 2, 6, 10, 64
+    g = torch.Generator().manual_seed(21)
+    ln = LayerNorm(d).cuda()
+    xz0 = torch.randn(B, H, W, 2 * d, generator=g).cuda()
+    t0 = torch.randn(B, H, W, d, generator=g).cuda()
+    gy, gx, gz = (torch.randn(s, generator=g).cuda() for s in ((B, H, W, d), (B, d, H, W), (B, H, W, d)))
+    res = []
+    for own in (True, False):
+        xz, t = xz0.clone().requires_grad_(), t0.clone().requires_grad_()
+        if own:
+            x, z = split_xz(xz)
+            if mode == "hook":
+                z.register_hook(lambda gr: gr * 2.0)
+            y = ln.forward_gated(t, z)
+        else:
+            x, z = xz[..., :d].permute(0, 3, 1, 2), xz[..., d:]
+            y = F.layer_norm(t, (d,), ln.weight, ln.bias, ln.eps) * F.silu(z)
+        loss = (y * gy).sum() + (x * gx).sum()
+        if mode == "second_consumer":
+            loss = loss + (z * gz).sum()
+        ln.zero_grad()
+        loss.backward()
+        res.append((xz.grad.clone(), t.grad.clone()))
+    want_xz = res[1][0].clone()
+    if mode == "hook":
+        want_xz[..., d:] *= 2.0
+    torch.testing.assert_close(res[0][0], want_xz, rtol=2e-5, atol=2e-5 * float(want_xz.abs().max()))
+    torch.testing.assert_close(res[0][1], res[1][1], rtol=2e-5, atol=2e-5 * float(res[1][1].abs().max()))
+    assert len(_handoff._XZ_GRAD_BUFFERS) <= _handoff._XZ_GRAD_KEEP

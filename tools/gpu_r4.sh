@@ -83,4 +83,9 @@ h)  # stacked x_proj / dt_proj GEMMs, residual in the out_proj GEMM: parity, the
     ( timeout 600 python bench.py --no-cpu-baseline ) > $out/bench_b8.log 2>&1; grep "^{" $out/bench_b8.log | cut -c1-700
     ( SIGMA_GEMM_XPROJ=fp32 timeout 600 python bench.py --no-cpu-baseline ) > $out/bench_b8_xproj_fp32.log 2>&1; grep "^{" $out/bench_b8_xproj_fp32.log | cut -c1-200
     ;;
+i)  # LayerNorm pass-through, explicit gradient-buffer hand-off, GEMM self test / validation, smoke with the row-lane kernels
+    ( time timeout 900 python -m pytest tests/test_gemm_gpu.py tests/test_pointwise_gpu.py tests/test_model_gpu.py -q --tb=short -x -k "not 480x640 and not 720x1280" ) > $out/pytest.log 2>&1; tail -4 $out/pytest.log | cut -c1-300
+    ( time timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" ) > $out/smoke.log 2>&1; tail -3 $out/smoke.log | cut -c1-300
+    ( timeout 600 python bench.py --no-cpu-baseline ) > $out/bench_b8.log 2>&1; grep "^{" $out/bench_b8.log | cut -c1-330
+    ;;
 esac
