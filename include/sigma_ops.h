@@ -146,6 +146,16 @@ int sigma_softmax_ce_fwd(const float *logits, const int64_t *labels, int64_t row
 int sigma_softmax_ce_bwd(const float *logits, const int64_t *labels, const float *lse, const float *scale, int64_t rows,
                          int32_t classes, int64_t ignore_index, float *dlogits, void *stream);
 
+/*   sigma_colscale_bwd
+ *       backward of  y = a + x * scale  with a per-channel `scale` on contiguous channels-last rows (rows, C): the residual
+ *       of the decoder block, x * scale1 + op(norm1(x)) and x * scale2 + conv_blk(norm2(x)) (vmamba.py:1800-1805):
+ *           dx[r][c] = dy[r][c] * scale[c]          dscale[c] += sum_r dy[r][c] * x[r][c]
+ *       in one pass over dy and x (the autograd formulation: two multiplies and a column reduction).  `dscale` is
+ *       ZERO-FILLED by the caller (float atomics, one per block and channel).  C % 4 == 0, C <= 1024, 16-byte aligned
+ *       operands.                                                                                                   */
+int sigma_colscale_bwd(const float *dy, const float *x, const float *scale, float *dx, float *dscale, int64_t rows,
+                       int32_t channels, void *stream);
+
 /*   sigma_layernorm_fwd / sigma_layernorm_bwd
  *       nn.LayerNorm(C, eps=1e-5, affine) over the last dimension of a contiguous (rows, C) fp32
  *       tensor: every LayerNorm of the hot path (vmamba.py:617, 724, 1183-1184, 1448-1449, 1693,

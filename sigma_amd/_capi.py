@@ -146,7 +146,7 @@ GEMM_AUX_SYMBOLS = ("sigma_gemm_selftest",)
 OPS_SYMBOLS = ("sigma_dwconv3x3_silu_fwd", "sigma_dwconv3x3_silu_bwd", "sigma_cross_merge_nhwc", "sigma_cross_split_nhwc",
                "sigma_layernorm_fwd", "sigma_layernorm_bwd", "sigma_layernorm_bwd_partial_rows", "sigma_transpose2d",
                "sigma_pair_sum_add", "sigma_upsample2x_nhwc", "sigma_plane_pool", "sigma_plane_scale",
-               "sigma_plane_dot", "sigma_plane_gate_bwd", "sigma_softmax_ce_fwd", "sigma_softmax_ce_bwd")
+               "sigma_plane_dot", "sigma_plane_gate_bwd", "sigma_softmax_ce_fwd", "sigma_softmax_ce_bwd", "sigma_colscale_bwd")
 
 # every symbol include/sigma_scan.h declares; tests check the library exports all of them
 EXPORTED_SYMBOLS = (
@@ -220,6 +220,9 @@ def load() -> ctypes.CDLL:
             fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p]
         elif name == "sigma_plane_gate_bwd":
             fn.argtypes = [P(GateBwdParams), ctypes.c_void_p]
+        elif name == "sigma_colscale_bwd":
+            fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                           ctypes.c_int32, ctypes.c_void_p]
         elif name == "sigma_softmax_ce_fwd":
             fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p,
                            ctypes.c_void_p, ctypes.c_void_p]

@@ -283,6 +283,40 @@ bool dispatch_nc4(int nc4, F&& f) {
 
 bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// ---- backward of  y = a + x * s  with a per-channel s on channels-last rows (CVSSDecoderBlock, vmamba.py:1800-1805) ------
+// dx = dy * s and ds += sum over rows of dy * x, one pass over dy and x.  A thread keeps ONE 16-byte column chunk for the
+// whole kernel (chunk = tid % (C / 4), row slot = tid / (C / 4); 256 / (C / 4) rows per block iteration), so its part of
+// ds lives in four registers; the row slots of a block meet in LDS and one thread per chunk adds the block's sum to ds
+// (float atomics: grid x C / 4 of them).  C % 4 == 0, C <= 1024.
+__global__ void __launch_bounds__(256) colscale_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                           const float* __restrict__ s, float* __restrict__ dx,
+                                                           float* __restrict__ ds, long rows, int C) {
+    extern __shared__ float part[];                       // [slots][C]
+    const int chunks = C >> 2;
+    const int slots = 256 / chunks;
+    const int slot = threadIdx.x / chunks, ch = threadIdx.x - slot * chunks;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (slot < slots) {
+        const float4 sv = *reinterpret_cast<const float4*>(s + 4 * ch);
+        for (long r = (long)blockIdx.x * slots + slot; r < rows; r += (long)gridDim.x * slots) {
+            const float4 g = *reinterpret_cast<const float4*>(dy + r * C + 4 * ch);
+            const float4 xv = *reinterpret_cast<const float4*>(x + r * C + 4 * ch);
+            *reinterpret_cast<float4*>(dx + r * C + 4 * ch) = make_float4(g.x * sv.x, g.y * sv.y, g.z * sv.z, g.w * sv.w);
+            acc.x = fmaf(g.x, xv.x, acc.x); acc.y = fmaf(g.y, xv.y, acc.y); acc.z = fmaf(g.z, xv.z, acc.z); acc.w = fmaf(g.w, xv.w, acc.w);
+        }
+        *reinterpret_cast<float4*>(part + slot * C + 4 * ch) = acc;
+    }
+    __syncthreads();
+    if (slot == 0) {
+        float4 t = acc;
+        for (int k = 1; k < slots; ++k) {
+            const float4 o = *reinterpret_cast<const float4*>(part + k * C + 4 * ch);
+            t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
+        }
+        atomicAdd(ds + 4 * ch, t.x); atomicAdd(ds + 4 * ch + 1, t.y); atomicAdd(ds + 4 * ch + 2, t.z); atomicAdd(ds + 4 * ch + 3, t.w);
+    }
+}
+
 unsigned stream_grid(long work_items) {
     long b = (work_items + 255) / 256;
     if (b > 256 * 16) b = 256 * 16;
@@ -324,6 +358,20 @@ int sigma_plane_scale(const float* x, const float* scale, float* out, int64_t pl
     const long work = vec ? planes * (hw / 4) : planes * hw;
     hipLaunchKernelGGL(sigma::plane_scale_kernel, dim3(sigma::stream_grid(work)), dim3(256), 0, static_cast<hipStream_t>(stream), x, scale, out,
                        (long)planes, (long)hw, vec);
+    return sigma::done();
+}
+
+int sigma_colscale_bwd(const float* dy, const float* x, const float* scale, float* dx, float* dscale, int64_t rows, int32_t channels,
+                       void* stream) {
+    if (rows < 0 || channels <= 0 || channels % 4 != 0 || channels > 1024) return SIGMA_OPS_ERR_ARG;
+    if (rows == 0) return SIGMA_OPS_OK;
+    if (!dy || !x || !scale || !dx || !dscale) return SIGMA_OPS_ERR_ARG;
+    if (!sigma::al16(dy) || !sigma::al16(x) || !sigma::al16(scale) || !sigma::al16(dx)) return SIGMA_OPS_ERR_ARG;
+    const int slots = 256 / (channels / 4);
+    long grid = (rows + slots - 1) / slots;
+    if (grid > 512) grid = 512;                       // two workgroups per CU: every block ends with C atomics on the same C addresses
+    hipLaunchKernelGGL(sigma::colscale_bwd_kernel, dim3((unsigned)grid), dim3(256), (size_t)slots * channels * sizeof(float),
+                       static_cast<hipStream_t>(stream), dy, x, scale, dx, dscale, (long)rows, (int)channels);
     return sigma::done();
 }
 

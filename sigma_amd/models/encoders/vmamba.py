@@ -35,7 +35,7 @@ import os
 
 from ...selective_scan import selective_scan_fn
 from ...layout import channels_first, channels_last, transpose_rows
-from ...pointwise import channel_gate, channel_gate_ok
+from ...pointwise import channel_gate, channel_gate_ok, scale_residual
 from ...ss2d_fused import (dwconv_silu, dwconv_silu_two_orders, selective_scan_ext, split_xz, ss2d_core,
                            ss2d_core_from_orders)
 
@@ -382,7 +382,7 @@ class CVSSDecoderBlock(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:       # (B, H, W, C)
         # x * scale1 + drop_path(op(norm1(x))): mask inside the branch, scale + add in one pass (branch first: the result
         # inherits its contiguous channels-last layout)
-        x = torch.addcmul(self.op(self.norm1(x), self.drop_path.draw(x)), x, self.scale1)
+        x = scale_residual(self.op(self.norm1(x), self.drop_path.draw(x)), x, self.scale1)
         y = self.conv_blk(channels_first(self.norm2(x)))
         # the channels-last operand first: the sum then comes out contiguous in (B, H, W, C) and the next block's
         # LayerNorm / in_proj read it in place (with the permuted conv output first, the result inherited its NCHW
@@ -390,7 +390,7 @@ class CVSSDecoderBlock(nn.Module):
         if y.is_cuda:
             # conv branch back to channels-last with the tiled transpose (its gradient then arrives contiguous in the
             # (B, C, H, W) order the gate's backward reads), residual scale + add in one pass
-            return torch.addcmul(channels_last(y), x, self.scale2)
+            return scale_residual(channels_last(y), x, self.scale2)
         return x * self.scale2 + y.permute(0, 2, 3, 1)
 
 

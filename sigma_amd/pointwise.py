@@ -98,6 +98,45 @@ def channel_gate(x: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor) -> torch.T
     return ChannelGateFn.apply(x, w1, w2)
 
 
+class ScaleResidualFn(torch.autograd.Function):
+    """a + x * scale with a per-channel scale on channels-last tensors -- the two residuals of the decoder block,
+    ``x * scale1 + op(norm1(x))`` and ``x * scale2 + conv_blk(norm2(x))`` (vmamba.py:1800-1805).  Forward: torch's
+    addcmul (one pass); backward: ONE pass over dy and x for dx = dy * scale and dscale = sum dy * x
+    (sigma_colscale_bwd) instead of two multiplies and a column reduction, and dy itself for the branch."""
+
+    @staticmethod
+    def forward(ctx, a, x, scale):
+        ctx.save_for_backward(x, scale)
+        return torch.addcmul(a, x, scale)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, scale = ctx.saved_tensors
+        C = x.shape[-1]
+        g = dy.contiguous()
+        xc = x.contiguous()
+        dx = torch.empty_like(xc)
+        ds = torch.zeros(C, device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            _capi.check(_capi.load().sigma_colscale_bwd(_p(g), _p(xc), _p(scale), _p(dx), _p(ds), xc.numel() // C, C, _stream()),
+                        "colscale_bwd")
+        return dy, dx, ds
+
+
+def scale_residual_ok(a: torch.Tensor, x: torch.Tensor, scale: torch.Tensor) -> bool:
+    C = x.shape[-1] if x.dim() else 0
+    return (a.is_cuda and x.is_cuda and a.dtype == torch.float32 and x.dtype == torch.float32 and scale.dtype == torch.float32
+            and tuple(a.shape) == tuple(x.shape) and tuple(scale.shape) == (C,) and C % 4 == 0 and 0 < C <= 1024
+            and x.is_contiguous() and x.data_ptr() % 16 == 0 and scale.data_ptr() % 16 == 0 and x.numel() > 0)
+
+
+def scale_residual(a: torch.Tensor, x: torch.Tensor, scale: torch.Tensor) -> torch.Tensor:
+    """a + x * scale (channel-wise) -- on the fused backward where it applies, torch.addcmul otherwise"""
+    if scale_residual_ok(a, x, scale) and torch.is_grad_enabled() and (x.requires_grad or scale.requires_grad or a.requires_grad):
+        return ScaleResidualFn.apply(a, x, scale)
+    return torch.addcmul(a, x, scale)
+
+
 class SoftmaxCEFn(torch.autograd.Function):
     """mean over the non-ignored pixels of -log softmax(logits)[label]; logits (rows, classes) contiguous"""
 

@@ -261,3 +261,26 @@ def test_in_proj_gradient_buffer_hand_off_takes_the_copying_path_when_z_has_comp
     torch.testing.assert_close(res[0][0], want_xz, rtol=2e-5, atol=2e-5 * float(want_xz.abs().max()))
     torch.testing.assert_close(res[0][1], res[1][1], rtol=2e-5, atol=2e-5 * float(res[1][1].abs().max()))
     assert len(_handoff._XZ_GRAD_BUFFERS) <= _handoff._XZ_GRAD_KEEP
+
+
+@pytest.mark.parametrize("shape", [(2, 12, 16, 96), (8, 30, 40, 384), (1, 7, 9, 192), (3, 5, 5, 1024), (2, 3, 4, 4), (1, 1, 1, 768)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_scale_residual_backward_in_one_pass_matches_addcmul(shape):
+    """pointwise.scale_residual (sigma_colscale_bwd): a + x * scale of the decoder block (vmamba.py:1800-1805) -- value and
+    the three gradients against torch.addcmul's autograd"""
+    from sigma_amd.pointwise import scale_residual, scale_residual_ok
+    C = shape[-1]
+    g = torch.Generator().manual_seed(C + shape[0])
+    a0, x0, s0, gy = (torch.randn(sh, generator=g).cuda() for sh in (shape, shape, (C,), shape))
+    res = []
+    for fn in (scale_residual, torch.addcmul):
+        a, x, s = a0.clone().requires_grad_(), x0.clone().requires_grad_(), s0.clone().requires_grad_()
+        assert scale_residual_ok(a, x, s)
+        y = fn(a, x, s)
+        y.backward(gy)
+        res.append((y.detach(), a.grad, x.grad, s.grad))
+    for got, want, name in zip(res[0], res[1], ("y", "da", "dx", "dscale")):
+        torch.testing.assert_close(got, want, rtol=2e-5, atol=2e-5 * float(want.abs().max()) + 1e-7, msg=lambda m, n=name: f"{n}: {m}")
+    # what the kernel does not take goes to addcmul: odd channel counts, no graph
+    y = scale_residual(torch.randn(2, 3, 5).cuda(), torch.randn(2, 3, 5).cuda(), torch.randn(5).cuda())
+    assert y.shape == (2, 3, 5)

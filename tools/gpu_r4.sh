@@ -88,4 +88,8 @@ i)  # LayerNorm pass-through, explicit gradient-buffer hand-off, GEMM self test 
     ( time timeout 600 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" ) > $out/smoke.log 2>&1; tail -3 $out/smoke.log | cut -c1-300
     ( timeout 600 python bench.py --no-cpu-baseline ) > $out/bench_b8.log 2>&1; grep "^{" $out/bench_b8.log | cut -c1-330
     ;;
+j)  # decoder scale-residual backward kernel
+    ( time timeout 900 python -m pytest tests/test_pointwise_gpu.py tests/test_model_gpu.py -q --tb=short -x -k "not 480x640 and not 720x1280" ) > $out/pytest.log 2>&1; grep -v "^  File" $out/pytest.log | tail -4 | cut -c1-300
+    ( timeout 600 python bench.py --no-cpu-baseline ) > $out/bench_b8.log 2>&1; grep "^{" $out/bench_b8.log | cut -c1-330
+    ;;
 esac
