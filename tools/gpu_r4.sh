@@ -92,4 +92,16 @@ j)  # decoder scale-residual backward kernel
     ( time timeout 900 python -m pytest tests/test_pointwise_gpu.py tests/test_model_gpu.py -q --tb=short -x -k "not 480x640 and not 720x1280" ) > $out/pytest.log 2>&1; grep -v "^  File" $out/pytest.log | tail -4 | cut -c1-300
     ( timeout 600 python bench.py --no-cpu-baseline ) > $out/bench_b8.log 2>&1; grep "^{" $out/bench_b8.log | cut -c1-330
     ;;
+final)  # end-of-round evidence on the final code
+    ( time AMD_LOG_LEVEL=1 timeout 1500 python -X faulthandler -m pytest tests -m gpu -q --tb=short ) > $out/pytest_gpu.log 2>&1; grep -v "^  File" $out/pytest_gpu.log | tail -4 | cut -c1-300
+    ( time timeout 300 python -c "import __graft_entry__ as g; g.smoke()" ) > $out/smoke.log 2>&1; tail -5 $out/smoke.log | head -2 | cut -c1-300
+    ( time timeout 900 python bench.py --steps 20 --warmup 5 --kernel-report $out/kernels.json ) > $out/bench.log 2>&1; grep "^{" $out/bench.log | cut -c1-500
+    R=$PWD; ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/trace -o b8 -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline ) > $out/trace.log 2>&1; grep "^{" $out/trace.log | cut -c1-200
+    tr=$(find $out/trace -name "*kernel_trace.csv" | head -1); python tools/prof_summary.py $tr --top 70 --last-ms 340 > $out/bench_kernel_stats.txt 2>&1; head -12 $out/bench_kernel_stats.txt | cut -c1-180
+    st=$(find $out/trace -name "*kernel_stats.csv" | head -1); [ -n "$st" ] && python tools/prof_summary.py $st --top 40 > $out/bench_rocprof_stats_whole_run.txt 2>&1
+    rm -f $tr
+    SCAN_BENCH_ARGS="--pitch 16" bash tools/gpu_pmc.sh r4_final/pmc enc_s2_b16 traffic > $out/pmc.txt 2>&1; grep -A3 "^== " $out/pmc.txt | grep -v "^--" | cut -c1-300
+    ( timeout 600 python bench.py --per-gpu-batch 1 --graph --no-cpu-baseline ) > $out/bench_b1_graph.log 2>&1; grep "^{" $out/bench_b1_graph.log | cut -c1-200
+    ( timeout 600 python bench.py --backbone sigma_base --height 720 --width 1280 --classes 5 --per-gpu-batch 1 --no-cpu-baseline ) > $out/bench_config5.log 2>&1; grep "^{" $out/bench_config5.log | cut -c1-200
+    ;;
 esac
