@@ -321,11 +321,45 @@ gemm_split3_kernel(const GemmArgs g) {
     // straight in the accumulator registers while the first k-steps are staged, no registers of their own and nothing
     // added to the epilogue.  Wave-uniform base + 32-bit element offsets (host: M * ldr < 2^31); rows / columns past the
     // matrix are clamped (their sums are never stored).
+    const bool res_rows = RES && (g.N & 3) == 0 && (g.ldr & 3) == 0 && (g.sR & 3) == 0 && (reinterpret_cast<uintptr_t>(g.R) & 15) == 0 &&
+                          (g.R2 == nullptr || (reinterpret_cast<uintptr_t>(g.R2) & 15) == 0) && SIGMA_GEMM_ROW_EPILOGUE;
     auto init_acc = [&](const Item& it) {
         if constexpr (!RES) { zero_acc(); return; }
         const float* __restrict__ r1 = g.R + it.r_off;
         const float* __restrict__ r2 = g.R2 ? g.R2 + it.r_off : nullptr;
         const unsigned ldr = (unsigned)g.ldr;
+        if (res_rows) {
+            // the mirror image of epilogue_rows: 16-byte loads of 8 x 128 contiguous bytes (both addends summed in
+            // registers), one 32 x 32 block at a time through the wave's 4 KB of LDS into accumulator order -- the
+            // direct form below is 64 (128 with two addends) dword loads per thread and tile.  The operand image is
+            // free here (between two tiles); the barrier keeps the first operand stores of the tile off the staging areas.
+            float* stage = reinterpret_cast<float*>(smem) + wave * 1024;
+            const int rdw = ((lane >> 5) << 2) * 32 + (lane & 31);
+            const int ld_row = lane >> 3, ld_col = (lane & 7) << 2;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = it.n0 + (wn * TN + j) * 32 + ld_col;
+                const unsigned cc_ = (unsigned)(col < g.N ? col : g.N - 4);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const long rbase = it.m0 + (wm * TM + i) * 32 + ld_row;
+                    f32x4_t v[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const long row = rbase + 8 * q;
+                        const unsigned o = (unsigned)(row < g.M ? row : g.M - 1) * ldr + cc_;
+                        v[q] = *reinterpret_cast<const f32x4_t*>(r1 + o);
+                        if (r2 != nullptr) v[q] += *reinterpret_cast<const f32x4_t*>(r2 + o);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4_t*>(stage + (ld_row + 8 * q) * 32 + ld_col) = v[q];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = stage[rdw + ((r & 3) + ((r >> 2) << 3)) * 32];
+                }
+            }
+            lds_barrier();
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int col = it.n0 + (wn * TN + j) * 32 + (lane & 31);

@@ -354,16 +354,17 @@ class SS2DCoreFn(torch.autograd.Function):
         # The projections on the split-operand MFMA kernels (stacked problems, weight stacks shared through a_mod, no
         # expanded weight copies, results written straight into their slices, weight gradients summed over the batch
         # inside the kernel) WHERE THEY BEAT the vendor fp32 batched GEMM + its helper passes -- measured per GEMM and
-        # stage in profiles/r04_xproj_bench.txt (tools/xproj_bench.py): x_proj forward everywhere, its weight gradient
-        # up to L = 1200, the rest only on the short sequences of the last stage.  SIGMA_GEMM_XPROJ=fp32 (or a reduction
+        # stage in profiles/r04_xproj_bench.txt (tools/xproj_bench.py): x_proj forward and its input gradient (with the
+        # scan's two du as epilogue addends: no pair-sum pass) everywhere, its weight gradient and dt_proj up to L = 1200,
+        # dt_proj's weight gradient on the last stage only, dt_proj's input gradient (M = dt_rank) nowhere.  SIGMA_GEMM_XPROJ=fp32 (or a reduction
         # length that is not a multiple of 4: dt_rank 6 of the 96-channel stage) keeps the vendor GEMMs; =all takes
         # every GEMM the kernels can (A/B runs).
         legal = bool(_XPROJ) and L % 4 == 0 and d % 4 == 0 and c % 2 == 0
         short = L <= 600 or _XPROJ_ALL
+        mid = L <= 1200 or _XPROJ_ALL
         own_x = legal
-        own_dt = legal and R % 4 == 0 and short
-        ctx.own = dict(xd=legal and short, xw=legal and (L <= 1200 or _XPROJ_ALL), dd=legal and R % 4 == 0 and _XPROJ_ALL,
-                       dw=legal and R % 4 == 0 and short)
+        own_dt = legal and R % 4 == 0 and mid
+        ctx.own = dict(xd=legal, xw=legal and mid, dd=legal and R % 4 == 0 and _XPROJ_ALL, dw=legal and R % 4 == 0 and short)
         if own_x:
             p4 = torch.empty((B, 4, c, L), device=xs2.device, dtype=torch.float32)
             _gemm.bgemm_nn(Wst, xs2.view(2 * B, d, L), p4.view(2 * B, 2 * c, L), pieces=_XPROJ)
