@@ -104,4 +104,14 @@ final)  # end-of-round evidence on the final code
     ( timeout 600 python bench.py --per-gpu-batch 1 --graph --no-cpu-baseline ) > $out/bench_b1_graph.log 2>&1; grep "^{" $out/bench_b1_graph.log | cut -c1-200
     ( timeout 600 python bench.py --backbone sigma_base --height 720 --width 1280 --classes 5 --per-gpu-batch 1 --no-cpu-baseline ) > $out/bench_config5.log 2>&1; grep "^{" $out/bench_config5.log | cut -c1-200
     ;;
+final2)  # end-of-round evidence after the last GEMM change: full suite, smoke, bench (driver-style), kernel trace
+    ( time AMD_LOG_LEVEL=1 timeout 1500 python -X faulthandler -m pytest tests -m gpu -q --tb=short ) > $out/pytest_gpu.log 2>&1; grep -v "^  File" $out/pytest_gpu.log | tail -4 | cut -c1-300
+    ( time timeout 300 python -c "import __graft_entry__ as g; g.smoke()" ) > $out/smoke.log 2>&1; tail -5 $out/smoke.log | head -2 | cut -c1-300
+    ( time timeout 900 python bench.py --steps 20 --warmup 5 --kernel-report $out/kernels.json ) > $out/bench.log 2>&1; grep "^{" $out/bench.log | cut -c1-500
+    R=$PWD; ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/$out/trace -o b8 -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline ) > $out/trace.log 2>&1; grep "^{" $out/trace.log | cut -c1-200
+    tr=$(find $out/trace -name "*kernel_trace.csv" | head -1); python tools/prof_summary.py $tr --top 70 --last-ms 332 > $out/bench_kernel_stats.txt 2>&1; head -12 $out/bench_kernel_stats.txt | cut -c1-180
+    st=$(find $out/trace -name "*kernel_stats.csv" | head -1); [ -n "$st" ] && python tools/prof_summary.py $st --top 40 > $out/bench_rocprof_stats_whole_run.txt 2>&1
+    rm -f $tr
+    ( timeout 600 python bench.py --per-gpu-batch 1 --graph --no-cpu-baseline ) > $out/bench_b1_graph.log 2>&1; grep "^{" $out/bench_b1_graph.log | cut -c1-200
+    ;;
 esac
