@@ -382,8 +382,11 @@ class CVSSDecoderBlock(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:       # (B, H, W, C)
         # x * scale1 + drop_path(op(norm1(x))): mask inside the branch, scale + add in one pass (branch first: the result
         # inherits its contiguous channels-last layout)
-        x = scale_residual(self.op(self.norm1(x), self.drop_path.draw(x)), x, self.scale1)
-        y = self.conv_blk(channels_first(self.norm2(x)))
+        # (LayerNorm(x), x): the gradient of the scaled residual joins the LayerNorm backward in its kernel (layernorm.py)
+        n1, x = self.norm1.forward_with_pass(x) if isinstance(self.norm1, LayerNorm) else (self.norm1(x), x)
+        x = scale_residual(self.op(n1, self.drop_path.draw(x)), x, self.scale1)
+        n2, x = self.norm2.forward_with_pass(x) if isinstance(self.norm2, LayerNorm) else (self.norm2(x), x)
+        y = self.conv_blk(channels_first(n2))
         # the channels-last operand first: the sum then comes out contiguous in (B, H, W, C) and the next block's
         # LayerNorm / in_proj read it in place (with the permuted conv output first, the result inherited its NCHW
         # strides and every following LayerNorm started with a transposing copy: 7 x 413 MB per step at 120 x 160)
