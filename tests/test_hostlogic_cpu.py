@@ -166,3 +166,34 @@ def test_gradient_buffer_hand_off_matches_only_the_registered_half():
         h.offer_xz_grad_buffer(torch.zeros(1, 1, 2, 8), 4)
     assert len(h._XZ_GRAD_BUFFERS) <= h._XZ_GRAD_KEEP
     assert h.claim_xz_grad_buffer(None, (1, 1, 2, 8)) is None
+
+
+def test_derived_parameter_cache_follows_the_parameter_version():
+    """ss2d_fused._derived_params: permuted / transposed weight copies and -exp(A_logs), cached per parameter version --
+    hit while nothing changed, rebuilt after an in-place update, a data swap, or for another parameter object"""
+    from sigma_amd import ss2d_fused as f
+    f._DERIVED.clear()
+    K, c, d, R, N = 4, 6, 8, 2, 4
+    xw, dw, al = (nn.Parameter(torch.randn(K, c, d)), nn.Parameter(torch.randn(K, d, R)), nn.Parameter(torch.randn(K * d, N)))
+    a = f._derived_params(xw, dw, al)
+    Wst, WstT, dtw, A = a
+    perm = [0, 2, 1, 3]
+    torch.testing.assert_close(Wst, xw.detach()[perm].reshape(2, 2 * c, d))
+    torch.testing.assert_close(WstT, Wst.transpose(1, 2))
+    torch.testing.assert_close(dtw, dw.detach()[perm])
+    torch.testing.assert_close(A, -torch.exp(al.detach()))
+    assert WstT.is_contiguous() and dtw.is_contiguous() and not any(t.requires_grad for t in a)
+    b = f._derived_params(xw, dw, al)
+    assert all(x is y for x, y in zip(a, b))                                  # hit
+    with torch.no_grad():
+        al.mul_(0.5)                                                           # what an optimizer step does: version bump
+    c2 = f._derived_params(xw, dw, al)
+    assert c2[3] is not A
+    torch.testing.assert_close(c2[3], -torch.exp(al.detach()))
+    xw.data = torch.randn(K, c, d)                                             # no version bump, another storage
+    d2 = f._derived_params(xw, dw, al)
+    torch.testing.assert_close(d2[0], xw.detach()[perm].reshape(2, 2 * c, d))
+    xw2 = nn.Parameter(xw.detach().clone())
+    e2 = f._derived_params(xw2, dw, al)
+    assert e2[0] is not d2[0]
+    assert all(x is y for x, y in zip(d2, f._derived_params(xw, dw, al)))      # the first one is still cached
