@@ -340,8 +340,16 @@ def _pair_sum_add(src: torch.Tensor, acc: torch.Tensor, n_outer: int, inner: int
 # load_state_dict, copy_ -- bumps the counter; ``p.data = ...`` changes the address), the entry holds a weak reference to
 # the parameter object it was built from.  Never inside a stream capture: a replayed graph runs no Python, so a captured
 # step must contain the derivation kernels themselves (parameters stepped by a captured optimizer would otherwise be
-# read through stale copies).
+# read through stale copies).  NOT seen by the key: in-place writes through ``param.data`` (a detached alias with its own
+# version counter) -- code that updates these parameters that way calls ``invalidate_derived_params()`` afterwards, or
+# runs with SIGMA_CACHE_DERIVED=0 (rebuild on every call, the behaviour up to round 3).
 _DERIVED = {}
+_CACHE_DERIVED = _os_early.environ.get("SIGMA_CACHE_DERIVED", "1") != "0"
+
+
+def invalidate_derived_params() -> None:
+    """drop every cached parameter-derived tensor (after in-place writes through ``param.data``)"""
+    _DERIVED.clear()
 
 
 def _derived_params(x_proj_weight, dt_projs_weight, A_logs):
@@ -355,7 +363,7 @@ def _derived_params(x_proj_weight, dt_projs_weight, A_logs):
         A = -torch.exp(A_logs.detach().float())
         return Wst, Wst.transpose(1, 2).contiguous(), dtw, A
 
-    if x_proj_weight.is_cuda and torch.cuda.is_current_stream_capturing():
+    if not _CACHE_DERIVED or (x_proj_weight.is_cuda and torch.cuda.is_current_stream_capturing()):
         return build()
     key = (x_proj_weight.data_ptr(), x_proj_weight._version, dt_projs_weight.data_ptr(), dt_projs_weight._version,
            A_logs.data_ptr(), A_logs._version)

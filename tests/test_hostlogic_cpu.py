@@ -197,3 +197,8 @@ def test_derived_parameter_cache_follows_the_parameter_version():
     e2 = f._derived_params(xw2, dw, al)
     assert e2[0] is not d2[0]
     assert all(x is y for x, y in zip(d2, f._derived_params(xw, dw, al)))      # the first one is still cached
+    # a write through .data is invisible to the key (documented): the caller invalidates
+    al.data.mul_(2.0)
+    assert f._derived_params(xw, dw, al)[3] is d2[3]
+    f.invalidate_derived_params()
+    torch.testing.assert_close(f._derived_params(xw, dw, al)[3], -torch.exp(al.detach()))
