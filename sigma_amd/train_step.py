@@ -84,6 +84,13 @@ def _distributed() -> bool:
     return dist.is_available() and dist.is_initialized()
 
 
+def _params_changed_behind_autograd() -> None:
+    """Parameters were just written in a way autograd's version counters do not see (a broadcast through ``p.data``, a
+    replayed optimizer graph): drop the SS2D blocks' cached parameter-derived tensors (ss2d_fused._derived_params)."""
+    from .ss2d_fused import invalidate_derived_params
+    invalidate_derived_params()
+
+
 def wrap_ddp(model: nn.Module, device: torch.device) -> nn.Module:
     """train.py:107.  find_unused_parameters=False: every parameter must receive a gradient."""
     if not _distributed():
@@ -98,6 +105,7 @@ def wrap_ddp(model: nn.Module, device: torch.device) -> nn.Module:
               static_graph=os.environ.get("SIGMA_DDP_STATIC", "0") == "1")
     net = nn.parallel.DistributedDataParallel(model, device_ids=ids, output_device=ids[0] if ids else None,
                                               find_unused_parameters=False, **kw)
+    _params_changed_behind_autograd()       # the constructor broadcasts rank 0's parameters into the replicas
     if os.environ.get("SIGMA_DDP_BF16", "0") == "1":
         # opt-in gradient compression: buckets travel as bf16, the optimizer still sees fp32 gradients
         from torch.distributed.algorithms.ddp_comm_hooks import default_hooks
@@ -149,6 +157,7 @@ def make_graphed_step(net: nn.Module, opt, batch: Tuple[torch.Tensor, ...], warm
 
     def step():
         graph.replay()
+        _params_changed_behind_autograd()   # the replay stepped the parameters without touching their version counters
         return loss
     step.graph = graph
     step.static = static            # the graph reads these buffers: they live as long as the step does
@@ -208,6 +217,7 @@ def make_graphed_ddp_step(model: nn.Module, opt, batch: Tuple[torch.Tensor, ...]
         dist.broadcast(p.data, 0)
     for b in model.buffers():
         dist.broadcast(b.data, 0)
+    _params_changed_behind_autograd()
     opt.state.clear()               # exp_avg / exp_avg_sq / step of steps taken before the broadcast are rank-specific
     static = tuple(t.clone() for t in batch)
     flat = flatten_grads(model)
@@ -242,6 +252,7 @@ def make_graphed_ddp_step(model: nn.Module, opt, batch: Tuple[torch.Tensor, ...]
         step.reduced_loss = red / world
         _allreduce_mean(flat, bf16_comm)
         g_opt.replay()
+        _params_changed_behind_autograd()
         return loss
     step.reduced_loss = None
     step.set_lr = lambda lr: set_lr(opt, lr)
