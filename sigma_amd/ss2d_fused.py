@@ -338,7 +338,8 @@ def _pair_sum_add(src: torch.Tensor, acc: torch.Tensor, n_outer: int, inner: int
 # handful of tiny launches per block and step.  They are cached per parameter VERSION: the key is
 # the parameters' storage addresses and autograd version counters (every in-place update -- optimizer step,
 # load_state_dict, copy_ -- bumps the counter; ``p.data = ...`` changes the address), the entry holds a weak reference to
-# the parameter object it was built from.  Never inside a stream capture: a replayed graph runs no Python, so a captured
+# the parameter object it was built from; optimizer steps drop the entries of the parameters they own (the fused
+# optimizers do not bump version counters).  Never inside a stream capture: a replayed graph runs no Python, so a captured
 # step must contain the derivation kernels themselves (parameters stepped by a captured optimizer would otherwise be
 # read through stale copies).  NOT seen by the key: in-place writes through ``param.data`` (a detached alias with its own
 # version counter) -- code that updates these parameters that way calls ``invalidate_derived_params()`` afterwards, or
@@ -350,6 +351,32 @@ _CACHE_DERIVED = _os_early.environ.get("SIGMA_CACHE_DERIVED", "1") != "0"
 def invalidate_derived_params() -> None:
     """drop every cached parameter-derived tensor (after in-place writes through ``param.data``)"""
     _DERIVED.clear()
+
+
+def _after_optimizer_step(optimizer, args, kwargs) -> None:
+    """Global optimizer post-step hook: the fused ("single kernel") optimizers update parameters WITHOUT bumping their
+    version counters (torch.optim.AdamW(fused=True): measured), so a step drops the entries built from any parameter the
+    optimizer owns.  The reference's groups leave the raw Mamba parameters out (utils/init_func.py:33-58): for its step
+    nothing is dropped and the cache lives across steps."""
+    if not _DERIVED:
+        return
+    owned = getattr(optimizer, "_sigma_owned_ids", None)
+    n = sum(len(g["params"]) for g in optimizer.param_groups)
+    if owned is None or owned[0] != n:
+        owned = (n, {id(q) for g in optimizer.param_groups for q in g["params"]})
+        try:
+            optimizer._sigma_owned_ids = owned
+        except Exception:
+            pass
+    for k in [k for k, ent in _DERIVED.items() if any(i in owned[1] for i in ent[3])]:
+        _DERIVED.pop(k, None)
+
+
+try:
+    from torch.optim.optimizer import register_optimizer_step_post_hook as _reg_post
+    _reg_post(_after_optimizer_step)
+except Exception:                                 # a torch without global optimizer hooks: no caching at all
+    _CACHE_DERIVED = False
 
 
 def _derived_params(x_proj_weight, dt_projs_weight, A_logs):
@@ -373,7 +400,7 @@ def _derived_params(x_proj_weight, dt_projs_weight, A_logs):
     val = build()
     if len(_DERIVED) > 4096:                      # parameters that died without a lookup: start over
         _DERIVED.clear()
-    _DERIVED[id(x_proj_weight)] = (key, weakref.ref(x_proj_weight), val)
+    _DERIVED[id(x_proj_weight)] = (key, weakref.ref(x_proj_weight), val, (id(x_proj_weight), id(dt_projs_weight), id(A_logs)))
     return val
 
 

@@ -197,6 +197,23 @@ def test_derived_parameter_cache_follows_the_parameter_version():
     e2 = f._derived_params(xw2, dw, al)
     assert e2[0] is not d2[0]
     assert all(x is y for x, y in zip(d2, f._derived_params(xw, dw, al)))      # the first one is still cached
+    # an optimizer that owns one of the parameters drops the entry when it steps (fused AdamW bumps no version counter);
+    # one that does not own them (the reference's groups) leaves it alone
+    kept = f._derived_params(xw, dw, al)
+    other = nn.Parameter(torch.randn(3))
+    other.grad = torch.ones(3)
+    torch.optim.AdamW([other], lr=0.1).step()
+    assert f._derived_params(xw, dw, al)[3] is kept[3]
+    al.grad = torch.ones_like(al)
+    try:
+        opt = torch.optim.AdamW([al], lr=0.1, fused=True)
+    except Exception:
+        opt = torch.optim.AdamW([al], lr=0.1)
+    opt.step()
+    fresh = f._derived_params(xw, dw, al)
+    assert fresh[3] is not kept[3]
+    torch.testing.assert_close(fresh[3], -torch.exp(al.detach()))
+    d2 = fresh
     # a write through .data is invisible to the key (documented): the caller invalidates
     al.data.mul_(2.0)
     assert f._derived_params(xw, dw, al)[3] is d2[3]
