@@ -225,6 +225,8 @@ def main():
         os.environ["SIGMA_GEMM"] = a.gemm
     from sigma_amd import selective_scan_cuda_core as core
     from sigma_amd.models.builder import EncoderDecoder
+    from sigma_amd.tuning import enable_tuned_gemms
+    enable_tuned_gemms()                           # vendor GEMMs look their solution up in the committed table (explicit, process-wide)
 
     timer = KernelTimer()
     core.set_launch_hook(timer)

@@ -649,9 +649,15 @@ __device__ __forceinline__ void scan_bwdr_summary_body(const BwdArgs& q, float* 
         sm[(((long)(seg - 1) * p.batch * (p.dim >> 6) + rowblock) * N + n0 + s) * 64 + lane] = make_float2(fast_exp2(Pacc[s]), ecar[s]);
 }
 
-// MODE 0: the backward proper; MODE 1: the summaries of segments 1 .. S-1; MODE 2: the backward as a chained walk
+// MODE 0: the backward proper; MODE 1: the summaries of segments 1 .. S-1; MODE 2: the backward as a chained walk.
+// Waves per SIMD the register allocation is sized for: the 64 KB of LDS of the backward proper (bwdr_lds_bytes) admit two
+// workgroups per CU = 2 waves per SIMD = 256 VGPRs; asking for 3 (round 4) capped the 16-state build at 168 VGPRs with 81
+// spilled to scratch for an occupancy the LDS never allowed.
+#ifndef SIGMA_BWDR_WPS
+#define SIGMA_BWDR_WPS 2
+#endif
 template <int NS, int MODE>
-__global__ void __launch_bounds__(256, MODE == 1 ? 4 : 3)
+__global__ void __launch_bounds__(256, MODE == 1 ? 4 : SIGMA_BWDR_WPS)
 scan_bwdr_kernel(const BwdArgs q) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int ntiles = (q.f.L + kRT - 1) / kRT;

@@ -42,8 +42,14 @@ class EncoderDecoder(nn.Module):
     def __init__(self, cfg=None, criterion=nn.CrossEntropyLoss(reduction="mean", ignore_index=255),
                  norm_layer=nn.BatchNorm2d):
         super().__init__()
-        from ..tuning import enable_tuned_gemms
-        enable_tuned_gemms()                                 # library GEMMs: committed solution table (sigma_amd/tuning.py)
+        # The committed solution table for the remaining vendor GEMMs (sigma_amd/tuning.py) switches PyTorch's TunableOp
+        # on PROCESS-WIDE: constructing a model does not do that behind the caller's back.  Entry points call
+        # sigma_amd.tuning.enable_tuned_gemms() themselves (bench.py, tools/); an unchanged train.py opts in with
+        # SIGMA_TUNED_GEMMS=1 in its environment.
+        import os
+        if os.environ.get("SIGMA_TUNED_GEMMS") == "1":
+            from ..tuning import enable_tuned_gemms
+            enable_tuned_gemms()
         self.norm_layer = norm_layer
         if cfg.backbone not in _BACKBONES:
             raise NotImplementedError(

@@ -60,8 +60,6 @@ class SelectiveScanFn(torch.autograd.Function):
     def backward(ctx, dout, *unused):
         u, delta, A, B, C, D, delta_bias, x = ctx.saved_tensors
         dout = _last_contig(dout)
-        if ctx.pitch == 16 and not _core.rowlane_ok(u, delta, B, C, dout):
-            dout = dout.contiguous().clone() if dout.data_ptr() % 16 else dout.contiguous()   # the row-lane backward wants aligned rows
         du, ddelta, dA, dB, dC, dD, ddelta_bias = _core.bwd_ext(
             u, delta, A, B, C, D, delta_bias, dout, x, ctx.delta_softplus, nrows=1, ckpt_pitch=ctx.pitch)
         if ctx.squeeze_B:

@@ -255,6 +255,14 @@ def bwd_ext(u, delta, A, B, C, D_, delta_bias_, dout, x_, delta_softplus, nrows:
     _check(dout.is_cuda, "dout must be a GPU tensor")
     _check(tuple(dout.shape) == (batch, dim >> dout_gshift, seqlen), "dout must have shape (batch_size, dim, seqlen)")
     _check(dout.stride(-1) == 1 or seqlen <= 1, "dout.stride(-1) must be 1")
+    if ckpt_pitch == _capi.SIGMA_SCAN_CKPT_PITCH_16 and batch > 0 and seqlen > 0 and (
+            dout.data_ptr() % 16 != 0 or any(s % 4 != 0 for s in dout.stride()[:-1])):
+        # The row-lane backward loads 16 bytes per lane: a gradient that autograd hands over as a narrowed / offset view
+        # is re-laid here (one copy) for EVERY caller instead of failing in the library (u / delta / B / C were checked
+        # by rowlane_ok before the forward picked this pitch; dout is only known now).
+        dout = dout.contiguous()
+        if dout.data_ptr() % 16 != 0:
+            dout = dout.clone()
     n_chunks = (seqlen + _capi.SIGMA_SCAN_CHUNK - 1) // _capi.SIGMA_SCAN_CHUNK
     if n_chunks > 1 or seqlen > _capi.SIGMA_SCAN_CKPT_PITCH:
         _check(x_ is not None, "x is required when seqlen > 2048")   # :320 (here: already above 1280)

@@ -60,7 +60,7 @@ _CKPT_ENV = _os.environ.get("SIGMA_CKPT_PITCH", "auto")
 def rowlane_pays(seqlen: int, dstate: int, rows: int, groups: int) -> bool:
     """Launch shapes on which the row-lane kernels (csrc/scan_fwdr.hip / scan_bwdr.hip, checkpoint pitch 16) beat the
     quad-row / 64-lane kernels in forward + backward time, from the shape-by-shape comparison on MI355X
-    (profiles/r04_rowlane_vs_auto.txt; tools/gpu_r4.sh e):
+    (profiles/r04_rowlane_vs_auto.txt; tools/scan_bench.py --pitch 16 against the automatic choice):
       * 16 (8) states: sequences of ~1200 at any batch (the dominant launch of the training step, (16,3072,1200): 1133
         against 1339 us), and every launch with few rows (one image per GPU: (2,768,19200) 930 / 985, (2,1536,4800)
         472 / 508, (2,3072,1200) 253 / 292) -- not L = 300 (its 19 tiles do not amortise the workgroup set-up) and not
@@ -354,29 +354,31 @@ def invalidate_derived_params() -> None:
 
 
 def _after_optimizer_step(optimizer, args, kwargs) -> None:
-    """Global optimizer post-step hook: the fused ("single kernel") optimizers update parameters WITHOUT bumping their
-    version counters (torch.optim.AdamW(fused=True): measured), so a step drops the entries built from any parameter the
+    """Optimizer post-step hook: the fused ("single kernel") optimizers update parameters WITHOUT bumping their version
+    counters (torch.optim.AdamW(fused=True): measured), so a step drops the entries built from any parameter the
     optimizer owns.  The reference's groups leave the raw Mamba parameters out (utils/init_func.py:33-58): for its step
-    nothing is dropped and the cache lives across steps."""
+    nothing is dropped and the cache lives across steps.  Reads the optimizer, never writes to it."""
     if not _DERIVED:
         return
-    owned = getattr(optimizer, "_sigma_owned_ids", None)
-    n = sum(len(g["params"]) for g in optimizer.param_groups)
-    if owned is None or owned[0] != n:
-        owned = (n, {id(q) for g in optimizer.param_groups for q in g["params"]})
-        try:
-            optimizer._sigma_owned_ids = owned
-        except Exception:
-            pass
-    for k in [k for k, ent in _DERIVED.items() if any(i in owned[1] for i in ent[3])]:
+    owned = {id(q) for g in optimizer.param_groups for q in g["params"]}
+    for k in [k for k, ent in _DERIVED.items() if any(i in owned for i in ent[3])]:
         _DERIVED.pop(k, None)
 
 
-try:
-    from torch.optim.optimizer import register_optimizer_step_post_hook as _reg_post
-    _reg_post(_after_optimizer_step)
-except Exception:                                 # a torch without global optimizer hooks: no caching at all
-    _CACHE_DERIVED = False
+_HOOK = {"state": None}                           # None: not tried yet; True: registered; False: this torch has no global hooks
+
+
+def _ensure_step_hook() -> bool:
+    """Registers the global optimizer hook the FIRST time an entry is about to be cached -- importing the package has no
+    process-wide side effect, and a process that never caches (SIGMA_CACHE_DERIVED=0, captured steps) never gets one."""
+    if _HOOK["state"] is None:
+        try:
+            from torch.optim.optimizer import register_optimizer_step_post_hook as _reg_post
+            _reg_post(_after_optimizer_step)
+            _HOOK["state"] = True
+        except Exception:                         # a torch without global optimizer hooks: no caching at all
+            _HOOK["state"] = False
+    return _HOOK["state"]
 
 
 def _derived_params(x_proj_weight, dt_projs_weight, A_logs):
@@ -390,7 +392,7 @@ def _derived_params(x_proj_weight, dt_projs_weight, A_logs):
         A = -torch.exp(A_logs.detach().float())
         return Wst, Wst.transpose(1, 2).contiguous(), dtw, A
 
-    if not _CACHE_DERIVED or (x_proj_weight.is_cuda and torch.cuda.is_current_stream_capturing()):
+    if not _CACHE_DERIVED or (x_proj_weight.is_cuda and torch.cuda.is_current_stream_capturing()) or not _ensure_step_hook():
         return build()
     key = (x_proj_weight.data_ptr(), x_proj_weight._version, dt_projs_weight.data_ptr(), dt_projs_weight._version,
            A_logs.data_ptr(), A_logs._version)

@@ -44,7 +44,7 @@ def test_struct_layout_matches_header(tmp_path):
     structs = (("sigma_scan_fwd_params", _capi.FwdParams), ("sigma_scan_bwd_params", _capi.BwdParams),
                ("sigma_dwconv_params", _capi.DwConvParams), ("sigma_merge_params", _capi.MergeParams),
                ("sigma_layernorm_params", _capi.LayerNormParams), ("sigma_transpose_params", _capi.TransposeParams),
-               ("sigma_gemm_params", _capi.GemmParams))
+               ("sigma_gemm_params", _capi.GemmParams), ("sigma_gate_bwd_params", _capi.GateBwdParams))
     for cname, cls in structs:
         lines.append(f'printf("%s %zu\\n", "{cname}", sizeof({cname}));')
         for fname, _ in cls._fields_:

@@ -16,6 +16,8 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     a = ap.parse_args()
     from sigma_amd.models.builder import EncoderDecoder
+    from sigma_amd.tuning import enable_tuned_gemms
+    enable_tuned_gemms()
     cfg = types.SimpleNamespace(backbone=a.backbone, decoder="MambaDecoder", num_classes=a.classes, image_height=a.height,
                                 image_width=a.width, pretrained_model=None, bn_eps=1e-3, bn_momentum=0.1)
     cwd = os.getcwd(); os.chdir("/tmp")
