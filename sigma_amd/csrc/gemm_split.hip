@@ -750,6 +750,7 @@ extern "C" int sigma_gemm_selftest(void* stream) {
                 }
         }
     }
+    (void)hipStreamSynchronize(s);      // every exit path: copies from / into the host buffers may still be enqueued
     (void)hipFree(dA); (void)hipFree(dB); (void)hipFree(dG); (void)hipFree(dC); (void)hipFree(dX); (void)hipFree(dW);
     delete[] hA; delete[] hB; delete[] hG; delete[] hC; delete[] hX; delete[] hW;
     return rc;

@@ -240,15 +240,22 @@ __device__ __forceinline__ void scan_bwdr_body(const BwdArgs& q, float* smem, co
         // chained walk: wait for the workgroup that walked the steps above (one relaxed poll loop in one lane, then an
         // agent-scope acquire, then the barrier: MI355X_MICROARCH.md, inter-workgroup visibility).  The producer ran this
         // row block FIRST and this is our LAST piece, so the flag is normally up; the spin is bounded all the same.
+        int* timed_out = reinterpret_cast<int*>(smem);                  // LDS is not in use yet
         if (tid == 0) {
             int* flag = q.chain_flag + ((b * p.G + g) * q.P + rbg);
-            for (int spin = 0; spin < (1 << 22) && __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0; ++spin)
+            int spin = 0;
+            for (; spin < (1 << 22) && __hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0; ++spin)
                 __builtin_amdgcn_s_sleep(16);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            *timed_out = spin >= (1 << 22);
         }
         __syncthreads();
+        // A wait that ran out (the producer is not resident: another stream's kernel holds its slot) must not pass for a
+        // result: the carry becomes NaN, which reaches du / ddelta / dA of this row block and every loss after it
+        const float poison = *timed_out ? __builtin_nanf("") : 0.0f;
+        __syncthreads();                                                // the flag word is free again before the tile loop writes LDS
 #pragma unroll
-        for (int s = 0; s < NS; ++s) ecar[s] = q.chain_carry[rb_carry + s * 64];
+        for (int s = 0; s < NS; ++s) ecar[s] = q.chain_carry[rb_carry + s * 64] + poison;
     }
     if (pc.cin == 1) {
         // reverse carry entering the right end = composition of the summaries of the segments after this one

@@ -65,12 +65,22 @@ def _selftest(dev) -> None:
     key = (dev.index if dev.index is not None else torch.cuda.current_device())
     if key in _SELFTESTED:
         return
+    if torch.cuda.is_current_stream_capturing():
+        # the self test allocates, copies from pageable host memory and synchronises: all illegal inside a capture
+        raise RuntimeError("sigma_amd.gemm: the first split-operand GEMM of this process on this device was issued inside a "
+                           "stream capture; run one step (or sigma_amd.gemm.selftest(device)) eagerly before capturing")
     with torch.cuda.device(dev):
         rc = _capi.load().sigma_gemm_selftest(ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
     if rc != 0:
         raise RuntimeError(f"sigma_gemm_selftest failed on {dev} (code {rc}): the split-operand GEMM kernels of this build do not "
                            f"compute A B^T exactly on an exactly representable problem; rebuild libsigma_hip.so with the supported ROCm")
     _SELFTESTED.add(key)
+
+
+def selftest(device=None) -> None:
+    """run the load-time self test of the GEMM kernels now (idempotent) -- before a capture whose first GEMM would
+    otherwise trigger it"""
+    _selftest(torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device))
 
 
 def _run(name, p, dev):

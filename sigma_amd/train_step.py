@@ -68,6 +68,18 @@ def make_optimizer(model: nn.Module, lr: float = 6e-5, weight_decay: float = 0.0
     return torch.optim.AdamW(groups, lr=lr, betas=(0.9, 0.999), weight_decay=weight_decay, **extra)
 
 
+def _tensor_lrs(opt) -> None:
+    """Before a capture: every group's learning rate becomes a device tensor (a Python float -- an optimizer not built by
+    ``make_optimizer(capturable=True)``, a float-lr checkpoint loaded with ``load_state_dict``, a manual
+    ``param_groups[i]['lr'] = v`` -- would be baked into the graph and ``set_lr`` would silently do nothing)."""
+    for g in opt.param_groups:
+        if not torch.is_tensor(g["lr"]):
+            dev = next((p.device for p in g["params"] if p.is_cuda), None)
+            if dev is None:
+                raise RuntimeError("graphed step: optimizer group without GPU parameters")
+            g["lr"] = torch.tensor(float(g["lr"]), device=dev, dtype=torch.float32)
+
+
 def set_lr(opt, lr: float) -> None:
     """The reference's per-iteration ``optimizer.param_groups[i]['lr'] = lr`` (train.py:173-177) for optimizers of
     ``make_optimizer``: tensor rates (capturable, i.e. graph-replayed steps) are written in place so that the next
@@ -140,6 +152,10 @@ def make_graphed_step(net: nn.Module, opt, batch: Tuple[torch.Tensor, ...], warm
     if _distributed():
         raise RuntimeError("make_graphed_step: single-process only (DDP buckets are not captured)")
     static = tuple(t.clone() for t in batch)
+    _tensor_lrs(opt)
+    from .gemm import gemm_mode, selftest
+    if gemm_mode() == "split3":
+        selftest(static[0].device)                           # not inside the capture (warmup=0)
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):                            # warm-up off the capture stream: lazy inits, LDS caps
@@ -221,6 +237,10 @@ def make_graphed_ddp_step(model: nn.Module, opt, batch: Tuple[torch.Tensor, ...]
     opt.state.clear()               # exp_avg / exp_avg_sq / step of steps taken before the broadcast are rank-specific
     static = tuple(t.clone() for t in batch)
     flat = flatten_grads(model)
+    _tensor_lrs(opt)
+    from .gemm import gemm_mode, selftest
+    if gemm_mode() == "split3":
+        selftest(static[0].device)
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
