@@ -29,6 +29,17 @@
 #define SIGMA_RL_DMA 1
 #endif
 
+// A/B build knob (round 5, measured and NOT taken: profiles/r05_bwdr_mfma_reduce_ab.txt).  1: the dB / dC terms of a
+// (position, state) are summed over the 64 lanes (= rows) of a wave on the MATRIX pipe -- v_mfma_f32_16x16x4_f32 with the
+// term as the A operand (A[i = lane & 15][k = lane >> 4]) and a one-hot B (column c = the position) adds the 4-lane sums
+// sum_k term[i + 16 k] into column c of a 16 x 16 accumulator (exact fp32), 128 MFMAs per tile and wave instead of 96 lane
+// swaps + 60 DPP adds.  Results identical to the oracle's tolerance, but (16,3072,1200,N16) runs in 1083 us against 748:
+// the f32 MFMA holds its SIMD for ~80 clocks next to dependent VALU work, not the 32 of a bare MFMA stream.
+// 0 (default): the transpose-reduce network on the vector ALU.
+#ifndef SIGMA_RL_MFMA
+#define SIGMA_RL_MFMA 0
+#endif
+
 #if SIGMA_RL_PROF
 __device__ unsigned long long g_bwdr_prof[16];
 #endif
@@ -227,8 +238,17 @@ __device__ __forceinline__ void scan_bwdr_body(const BwdArgs& q, float* smem, co
         const long slab = (((long)rbg * p.batch + b) * p.G + g) * (long)N * L;
         oB = q.ws_dB + slab; oC = q.ws_dC + slab; o_nsB = L; o_nsC = L;
     }
+#if SIGMA_RL_MFMA
+    // after the folds of the accumulators (below) lane l holds the total of array l >> 5 at memory position l & 15 (lanes l
+    // and l ^ 16 hold the same total and store it twice)
+    const int o_pos = lane & 15;
+    float oh[T];                                                    // B operand of the reducing MFMA: one-hot column c
+#pragma unroll
+    for (int c = 0; c < T; ++c) oh[c] = (lane & 15) == c ? 1.0f : 0.0f;
+#else
     // lane l of rl_reduce_finish: array l >> 5, memory position below (lanes l and l ^ 1 hold the same total and store it twice)
     const int o_pos = ((lane >> 1) & 1) * 8 + ((lane >> 2) & 1) * 2 + ((lane >> 3) & 1) + ((lane >> 4) & 1) * 4;
+#endif
     float* __restrict__ o_lane = (lane < 32 ? oB + (long)n0 * o_nsB : oC + (long)n0 * o_nsC) + o_pos;
     const int o_ns_lane = (int)(lane < 32 ? o_nsB : o_nsC);
 
@@ -322,6 +342,7 @@ __device__ __forceinline__ void scan_bwdr_body(const BwdArgs& q, float* smem, co
         // after its requests (the touch, NS checkpoint loads, NS dB/dC stores, du, ddelta), which stay in
         // flight; the partial tile may skip some of them, so it (and the step after it: the caller waits) drains the counter.
         if (TAIL) rl_dma_wait(); else rl_dma_wait_keep<3 + 2 * NS>();
+        RLPROF(8)                                                   // wait for this tile's u / delta / dout (LDS-DMA)
         const v4f uu = sRaw[tid], dd = sRaw[256 + tid];
         v4f g4 = sRaw[512 + tid];
         const v4f zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -339,6 +360,7 @@ __device__ __forceinline__ void scan_bwdr_body(const BwdArgs& q, float* smem, co
             const int mn = tile_of(more ? st - 1 : st);
 #if SIGMA_RL_DMA
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the reads of this tile's bytes are done
+            RLPROF(9)                                               // raw operand reads back from LDS (+ B / C of the first state)
             request(mn);
 #else
             u_nx = rl_load4u(u_blk + u_off - 4 * cc, T * mn + 4 * cc, more && T * mn + 4 * cc < L);
@@ -347,6 +369,7 @@ __device__ __forceinline__ void scan_bwdr_body(const BwdArgs& q, float* smem, co
 #endif
             touch_nx = bc_touch[T * mn];
         }
+        RLPROF(10)                                                  // requests of the next tile
         {
             v4f dl4, dlu4, sg4;
 #pragma unroll
@@ -376,7 +399,11 @@ __device__ __forceinline__ void scan_bwdr_body(const BwdArgs& q, float* smem, co
         rl_barrier();
         RLPROF(1)                                                   // barrier 1
 
+#if SIGMA_RL_MFMA
+        float psB[NS], psC[NS];                                     // 4-lane sums of the half walked first, per state
+#else
         float psave[NS];
+#endif
 #pragma unroll
         for (int hs = 1; hs >= 0; --hs) {
             const int hm = REV ? 1 - hs : hs;                       // memory half
@@ -429,7 +456,11 @@ __device__ __forceinline__ void scan_bwdr_body(const BwdArgs& q, float* smem, co
                 }
                 // ---- reverse: dx_k = g_k C_k + e_{k+1}, e_k = a_k dx_k
                 float e = ecar[s];
+#if SIGMA_RL_MFMA
+                v4f accB = {0.0f, 0.0f, 0.0f, 0.0f}, accC = {0.0f, 0.0f, 0.0f, 0.0f};
+#else
                 float w[H];
+#endif
 #pragma unroll
                 for (int kk = H - 1; kk >= 0; --kk) {
                     const int k = REV ? H - 1 - kk : kk;
@@ -441,7 +472,33 @@ __device__ __forceinline__ void scan_bwdr_body(const BwdArgs& q, float* smem, co
                     const float t = e * xprev;                      // dx * a_k * x_{k-1}
                     sAx[k] = fmaf(A2[s], t, sAx[k]);                // x ln 2 in the epilogue
                     dAacc[s] = fmaf(dl[k], t, dAacc[s]);
-                    // this row's terms of dB[n, l] and dC[n, l]: the two wave halves summed at once
+                    // this row's terms of dB[n, l] and dC[n, l]
+#if SIGMA_RL_MFMA
+#if SIGMA_RL_ABL & 64
+                    accB[0] += dx * dlu[k]; accC[0] += gg[k] * xs[k];
+#else
+                    accB = __builtin_amdgcn_mfma_f32_16x16x4f32(dx * dlu[k], oh[H * hm + k], accB, 0, 0, 0);
+                    accC = __builtin_amdgcn_mfma_f32_16x16x4f32(gg[k] * xs[k], oh[H * hm + k], accC, 0, 0, 0);
+#endif
+                }
+                ecar[s] = e;
+                // accumulator of lane l: column l & 15 (position), rows 4 (l >> 4) + r of the 16 four-lane sums
+                const float tB = (accB[0] + accB[1]) + (accB[2] + accB[3]), tC = (accC[0] + accC[1]) + (accC[2] + accC[3]);
+                if (hs == 1) {
+                    psB[s] = tB; psC[s] = tC;                       // columns of the other half are zero in these
+                } else {
+#if SIGMA_RL_ABL & 64
+                    const float tot = (tB + psB[s]) + (tC + psC[s]);
+#else
+                    // lanes l, l + 16, l + 32, l + 48 hold the four quarters of position l & 15: wave halves (dB to lanes
+                    // 0-31, dC to 32-63), then DPP row pairs
+                    const float f = rl_fold32(tB + psB[s], tC + psC[s]);
+                    const float tot = rl_fold16(f, f);
+#endif
+                    if (!TAIL || T * m + o_pos < L) o_lane[s * o_ns_lane + T * m] = tot;
+                }
+#else
+                    // ... the two wave halves summed at once
 #if SIGMA_RL_ABL & 64
                     w[k] = dx * dlu[k] + gg[k] * xs[k];
 #else
@@ -464,6 +521,7 @@ __device__ __forceinline__ void scan_bwdr_body(const BwdArgs& q, float* smem, co
 #endif
                     if (!TAIL || T * m + o_pos < L) o_lane[s * o_ns_lane + T * m] = tot;
                 }
+#endif
                 __builtin_amdgcn_sched_barrier(0);
                 RLPROF(4)                                           // state loop
             }
@@ -501,6 +559,10 @@ __device__ __forceinline__ void scan_bwdr_body(const BwdArgs& q, float* smem, co
 #endif
             const v4f dle = sProc[rl_unit(cc, rr)], ge = sProc[512 + rl_unit(cc, rr)];
             const v4f ue = sProc[768 + rl_unit(cc, rr)], sge = sProc[1024 + rl_unit(cc, rr)];
+#if SIGMA_RL_PROF
+            asm volatile("" : "+v"(S1), "+v"(S2));
+#endif
+            RLPROF(11)                                              // epilogue: exchange reads
             v4f duv, ddv;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {

@@ -33,3 +33,19 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(autouse=True, scope="module")
+def _settle_gpu_state_between_modules():
+    """Every test file of the GPU suite starts from a settled process: objects of the previous file that own GPU runtime
+    state (captured HIP graphs and their private pools, process groups, DDP reducers) are destroyed HERE, at a known
+    point, instead of whenever the cyclic collector next runs inside another file's kernels; the device is idle and the
+    caching allocator's unused blocks are back with the driver (vendor libraries allocate outside it)."""
+    yield
+    import gc
+
+    import torch
+    gc.collect()
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()

@@ -13,7 +13,8 @@ from sigma_amd import _capi  # noqa: E402
 from sigma_amd import selective_scan_cuda_core as core  # noqa: E402
 from tools.scan_bench import SHAPES, make  # noqa: E402
 
-PH = ["prologue", "barrier1", "lds_reads", "scalar_wait", "state_loop", "exch_write", "barrier2", "epilogue"]
+PH = ["prologue", "barrier1", "lds_reads", "scalar_wait", "state_loop", "exch_write", "barrier2", "epilogue",
+      "p_dma_wait", "p_raw_reads", "p_requests", "e_exch_reads"]      # 8-11: parts of the backward's prologue / epilogue (0 = the rest)
 
 
 def read():
@@ -36,12 +37,12 @@ def main():
         r = read()
         w = max(r[15], 1)
         print(json.dumps({"shape": name, "kernel": "fwd", "waves": r[15], "total_per_wave": sum(r[:12]) / w,
-                          **{PH[i]: round(r[i] / w) for i in range(8)}}))
+                          **{PH[i]: round(r[i] / w) for i in range(12)}}))
         core.bwd_ext(u, delta, A, Bm, Cm, D, bias, dout, x, True, ckpt_pitch=16)
         r = read()
         w = max(r[15], 1)
         print(json.dumps({"shape": name, "kernel": "bwd", "waves": r[15], "total_per_wave": sum(r[:12]) / w,
-                          **{PH[i]: round(r[i] / w) for i in range(8)}}))
+                          **{PH[i]: round(r[i] / w) for i in range(12)}}))
 
 
 if __name__ == "__main__":
