@@ -658,8 +658,28 @@ class Backbone_VSSM(nn.Module):
                 rename(f"layers.{i}.blocks.{j}.self_attention", f"layers.{i}.blocks.{j}.op")
         return super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
+    def _patch_embed(self, x: torch.Tensor) -> torch.Tensor:
+        """patch_embed = Conv2d(kernel = stride = patch) -> (B, H, W, C) -> LayerNorm (vmamba.py:1965-1969).  A convolution
+        whose windows do not overlap IS a matrix product of the flattened patches: on the GPU it runs on the
+        split-operand bf16 MFMA kernels like every other projection (csrc/gemm_split.hip: forward nt, weight gradient tn;
+        the images need no gradient), its result is channels-last as the LayerNorm wants it (no transposing copy), and
+        the vendor convolution library is out of the stem.  SIGMA_GEMM=fp32 / CPU tensors keep nn.Conv2d."""
+        conv, norm = self.patch_embed[0], self.patch_embed[2]
+        p = conv.kernel_size
+        if (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and isinstance(conv, nn.Conv2d) and _gemm.gemm_mode() == "split3"
+                and conv.stride == p and conv.padding == (0, 0) and conv.dilation == (1, 1) and conv.groups == 1
+                and x.shape[2] % p[0] == 0 and x.shape[3] % p[1] == 0 and (conv.in_channels * p[0] * p[1]) % 4 == 0
+                and conv.weight.dtype == torch.float32):
+            B, C, H, W = x.shape
+            hp, wp = H // p[0], W // p[1]
+            # one gather: row (b, i, j) = the patch's (c, ky, kx) values in the order of the weight's trailing dimensions
+            cols = x.view(B, C, hp, p[0], wp, p[1]).permute(0, 2, 4, 1, 3, 5).reshape(B * hp * wp, C * p[0] * p[1])
+            y = _gemm.linear(cols, conv.weight.view(conv.out_channels, -1), conv.bias)
+            return norm(y.view(B, hp, wp, conv.out_channels))
+        return self.patch_embed(x)
+
     def forward(self, x: torch.Tensor):
-        x = self.patch_embed(x)
+        x = self._patch_embed(x)
         outs = []
         for i, layer in enumerate(self.layers):
             o = layer.blocks(x)
