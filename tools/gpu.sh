@@ -20,7 +20,7 @@ driver() {  # n, out dir
   : > $out/driver_cmd_summary.txt
   for i in $(seq 1 $n); do
     ( time $DRIVER_CMD ) > $out/pytest_$i.log 2>&1; rc=$?
-    { echo "run $i of $n: \$ $DRIVER_CMD   -> rc=$rc"; grep -v "^  File" $out/pytest_$i.log | grep -v "^$" | tail -5 | cut -c1-200; } | tee -a $out/driver_cmd_summary.txt
+    { echo "run $i of $n: \$ $DRIVER_CMD   -> rc=$rc"; grep -E " passed| failed| error|^real" $out/pytest_$i.log | tail -3 | cut -c1-200; } | tee -a $out/driver_cmd_summary.txt
   done
   ( time timeout 300 python -c "import __graft_entry__ as g; g.smoke()" ) > $out/smoke.log 2>&1; echo "smoke rc=$?" | tee -a $out/driver_cmd_summary.txt
   grep "smoke ok" $out/smoke.log | cut -c1-200 | tee -a $out/driver_cmd_summary.txt
