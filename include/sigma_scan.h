@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SIGMA_SCAN_ABI_VERSION 8
+#define SIGMA_SCAN_ABI_VERSION 9
 
 /* dtype of u, delta, B, C, out, dout, du, ddelta  (input_t of the reference,
  * selective_scan.cpp:174: float / half / bfloat16).  A, D, delta_bias, x, dA,
@@ -232,6 +232,15 @@ int sigma_scan_debug_read(uint64_t out16[16]);
 /* On-device self test of the wave64 DPP scan primitives against a serial loop.
  * Returns 0 when every lane matches; enqueues on `stream` and synchronises it. */
 int sigma_scan_selftest(void *stream);
+
+/* ABI 9.  Self test of the row-lane kernels (ckpt_pitch 16; csrc/scan_fwdr.hip / scan_bwdr.hip): one small problem --
+ * two groups of 64 rows, the second walked backwards, 16 states, 148 positions (a partial last tile), softplus, D and
+ * delta_bias -- through sigma_selective_scan_fwd / _bwd, forward and all seven gradients compared with a host recurrence in
+ * double precision (scaled max error < 2e-4).  These kernels retire their vector-memory requests with hand-counted
+ * s_waitcnt values and pin their scalar-operand waits with scheduling barriers: a toolchain that schedules them
+ * differently fails here, loudly.  Allocates, copies and synchronises `stream` (not for use inside a stream capture); the
+ * host binding runs it once per process and device before the first ckpt_pitch-16 launch.  0 = pass. */
+int sigma_scan_rowlane_selftest(void *stream);
 
 #ifdef __cplusplus
 }

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SIGMA_HIP_LIB lets a benchmark A/B an experimental build of the same ABI; default is the in-tree library
 LIB_PATH = os.environ.get("SIGMA_HIP_LIB") or os.path.join(_HERE, "lib", "libsigma_hip.so")
 
-SIGMA_SCAN_ABI_VERSION = 8
+SIGMA_SCAN_ABI_VERSION = 9
 SIGMA_SCAN_CHUNK = 2048
 SIGMA_SCAN_CKPT_PITCH = 1280
 SIGMA_SCAN_CKPT_PITCH_FINE = 640
@@ -162,6 +162,7 @@ EXPORTED_SYMBOLS = (
     "sigma_scan_bwd_plan",
     "sigma_scan_debug_read",
     "sigma_scan_selftest",
+    "sigma_scan_rowlane_selftest",
 )
 
 _lib: Optional[ctypes.CDLL] = None
@@ -203,6 +204,8 @@ def load() -> ctypes.CDLL:
     lib.sigma_scan_bwd_plan.restype = ctypes.c_int
     lib.sigma_scan_selftest.argtypes = [ctypes.c_void_p]
     lib.sigma_scan_selftest.restype = ctypes.c_int
+    lib.sigma_scan_rowlane_selftest.argtypes = [ctypes.c_void_p]
+    lib.sigma_scan_rowlane_selftest.restype = ctypes.c_int
     lib.sigma_scan_debug_read.argtypes = [P(ctypes.c_uint64 * 16)]
     lib.sigma_scan_debug_read.restype = ctypes.c_int
     for name in OPS_SYMBOLS:

@@ -12,7 +12,9 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cmath>
 #include <string>
+#include <vector>
 
 namespace {
 
@@ -915,6 +917,159 @@ int sigma_scan_selftest(void* stream) {
         return fail(SIGMA_ERR_LAUNCH,
                     "wave-scan selftest mismatch: fwd=%g rev=%g prev=%g next=%g sum=%g mfwd=%g mrev=%g (max abs errors)",
                     h[1], h[2], h[3], h[4], h[5], h[6], h[7]);
+    return SIGMA_OK;
+}
+
+// Self test of the row-lane kernels (scan_fwdr.hip / scan_bwdr.hip), in the spirit of sigma_gemm_selftest: their vector
+// memory waits are COUNTED by hand (LDS-DMA requests retired with s_waitcnt vmcnt(3 + 2 NS) while younger stores stay
+// in flight), their scalar operand waits pinned with scheduling barriers -- a toolchain that schedules differently must
+// fail HERE, loudly, not in a training run.  One small problem through the public entry points (two groups of 64 rows,
+// the second walked backwards, 16 states, 9 full tiles + a partial one, softplus, D and bias): forward and all seven
+// gradients against a host recurrence in double precision.  Synchronises `stream`.  0 = pass.
+int sigma_scan_rowlane_selftest(void* stream) {
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const int Bt = 1, G = 2, RPG = 64, KD = G * RPG, L = 148, N = 16, NT = (L + 15) / 16;
+    const size_t nrow = (size_t)KD * L, nbc = (size_t)G * N * L, nx = (size_t)KD * 2 * NT * N;
+    std::vector<float> u(nrow), dl(nrow), g(nrow), A((size_t)KD * N), Bm(nbc), Cm(nbc), D(KD), bias(KD);
+    unsigned st = 2463534242u;
+    auto rnd = [&]() { st = st * 1664525u + 1013904223u; return (float)((st >> 8) & 0xffff) / 32768.0f - 1.0f; };   // [-1, 1)
+    for (auto& v : u) v = rnd();
+    for (auto& v : dl) v = 0.5f * rnd();
+    for (auto& v : g) v = rnd();
+    for (auto& v : Bm) v = rnd();
+    for (auto& v : Cm) v = rnd();
+    for (int r = 0; r < KD; ++r) {
+        D[r] = rnd(); bias[r] = -1.0f + 0.5f * rnd();
+        for (int n = 0; n < N; ++n) A[(size_t)r * N + n] = -0.1f * (float)(n + 1) * (1.0f + 0.1f * (float)(r % 3));
+    }
+    const unsigned rev_mask = 0b10;
+    // ---- host reference (double)
+    std::vector<double> r_out(nrow), r_du(nrow), r_dd(nrow), r_dA((size_t)KD * N, 0.0), r_dB(nbc, 0.0), r_dC(nbc, 0.0), r_dD(KD, 0.0), r_db(KD, 0.0);
+    {
+        std::vector<double> dsp(L), sg(L), xs((size_t)L * N), a((size_t)L * N);
+        for (int r = 0; r < KD; ++r) {
+            const int gi = r / RPG;
+            const bool rev = (rev_mask >> gi) & 1u;
+            auto pos = [&](int t) { return rev ? L - 1 - t : t; };          // memory position of scan step t
+            for (int l = 0; l < L; ++l) {
+                const double raw = (double)dl[(size_t)r * L + l] + bias[r];
+                dsp[l] = raw > 20.0 ? raw : std::log1p(std::exp(raw));
+                sg[l] = raw > 20.0 ? 1.0 : 1.0 / (1.0 + std::exp(-raw));
+            }
+            std::vector<double> x(N, 0.0);
+            for (int t = 0; t < L; ++t) {
+                const int l = pos(t);
+                double y = (double)D[r] * u[(size_t)r * L + l];
+                for (int n = 0; n < N; ++n) {
+                    const double an = std::exp(dsp[l] * A[(size_t)r * N + n]);
+                    x[n] = an * x[n] + dsp[l] * u[(size_t)r * L + l] * Bm[((size_t)gi * N + n) * L + l];
+                    a[(size_t)t * N + n] = an; xs[(size_t)t * N + n] = x[n];
+                    y += (double)Cm[((size_t)gi * N + n) * L + l] * x[n];
+                }
+                r_out[(size_t)r * L + l] = y;
+            }
+            std::vector<double> e(N, 0.0);
+            for (int t = L - 1; t >= 0; --t) {
+                const int l = pos(t);
+                const double gl = g[(size_t)r * L + l], ul = u[(size_t)r * L + l];
+                double s1 = 0.0, s2 = 0.0;
+                for (int n = 0; n < N; ++n) {
+                    const double dx = gl * Cm[((size_t)gi * N + n) * L + l] + e[n];
+                    const double xprev = t > 0 ? xs[(size_t)(t - 1) * N + n] : 0.0;
+                    const double an = a[(size_t)t * N + n], bn = Bm[((size_t)gi * N + n) * L + l];
+                    e[n] = an * dx;
+                    s1 += dx * bn;
+                    s2 += dx * an * xprev * A[(size_t)r * N + n];
+                    r_dA[(size_t)r * N + n] += dx * an * xprev * dsp[l];
+                    r_dB[((size_t)gi * N + n) * L + l] += dx * dsp[l] * ul;
+                    r_dC[((size_t)gi * N + n) * L + l] += gl * xs[(size_t)t * N + n];
+                }
+                r_du[(size_t)r * L + l] = (double)D[r] * gl + dsp[l] * s1;
+                const double dd = (ul * s1 + s2) * sg[l];
+                r_dd[(size_t)r * L + l] = dd;
+                r_dD[r] += gl * ul;
+                r_db[r] += dd;
+            }
+        }
+    }
+    // ---- device
+    sigma_scan_bwd_params q;
+    std::memset(&q, 0, sizeof(q));
+    sigma_scan_fwd_params& p = q.fwd;
+    p.batch = Bt; p.dim = KD; p.seqlen = L; p.dstate = N; p.n_groups = G; p.n_chunks = (L + SIGMA_SCAN_CHUNK - 1) / SIGMA_SCAN_CHUNK;
+    p.io_dtype = SIGMA_DTYPE_F32; p.delta_softplus = 1; p.rev_group_mask = rev_mask; p.ckpt_pitch = SIGMA_SCAN_CKPT_PITCH_16;
+    p.u_batch_stride = p.delta_batch_stride = p.out_batch_stride = (int64_t)nrow; p.u_d_stride = p.delta_d_stride = p.out_d_stride = L;
+    p.A_d_stride = N; p.A_dstate_stride = 1;
+    p.B_batch_stride = p.C_batch_stride = (int64_t)nbc; p.B_group_stride = p.C_group_stride = (int64_t)N * L; p.B_dstate_stride = p.C_dstate_stride = L;
+    q.dout_batch_stride = q.du_batch_stride = q.ddelta_batch_stride = (int64_t)nrow; q.dout_d_stride = q.du_d_stride = q.ddelta_d_stride = L;
+    q.dA_d_stride = N; q.dA_dstate_stride = 1;
+    q.dB_batch_stride = q.dC_batch_stride = (int64_t)nbc; q.dB_group_stride = q.dC_group_stride = (int64_t)N * L; q.dB_dstate_stride = q.dC_dstate_stride = L;
+    // one allocation, every tensor 256-byte aligned
+    auto al = [](size_t n) { return (n + 63) / 64 * 64; };
+    const size_t o_u = 0, o_dl = o_u + al(nrow), o_g = o_dl + al(nrow), o_A = o_g + al(nrow), o_B = o_A + al((size_t)KD * N), o_C = o_B + al(nbc),
+                 o_D = o_C + al(nbc), o_bias = o_D + al(KD), o_out = o_bias + al(KD), o_x = o_out + al(nrow), o_du = o_x + al(nx),
+                 o_dd = o_du + al(nrow), o_dA = o_dd + al(nrow), o_dB = o_dA + al((size_t)KD * N), o_dC = o_dB + al(nbc), o_dD = o_dC + al(nbc),
+                 o_db = o_dD + al(KD), o_end = o_db + al(KD);
+    float* dev = nullptr;
+    hipError_t e = hipMalloc(&dev, o_end * sizeof(float));
+    if (e != hipSuccess) return fail(SIGMA_ERR_NO_DEVICE, "row-lane selftest: hipMalloc failed: %s", hipGetErrorString(e));
+    void* ws_f = nullptr; void* ws_b = nullptr;
+    int rc = SIGMA_OK;
+    std::vector<float> h_out(nrow), h_du(nrow), h_dd(nrow), h_dA((size_t)KD * N), h_dB(nbc), h_dC(nbc), h_dD(KD), h_db(KD);
+    auto up = [&](size_t off, const std::vector<float>& v) { return hipMemcpyAsync(dev + off, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice, s); };
+    auto down = [&](std::vector<float>& v, size_t off) { return hipMemcpyAsync(v.data(), dev + off, v.size() * sizeof(float), hipMemcpyDeviceToHost, s); };
+    do {
+        e = hipMemsetAsync(dev, 0, o_end * sizeof(float), s);
+        if (e == hipSuccess) e = up(o_u, u);
+        if (e == hipSuccess) e = up(o_dl, dl);
+        if (e == hipSuccess) e = up(o_g, g);
+        if (e == hipSuccess) e = up(o_A, A);
+        if (e == hipSuccess) e = up(o_B, Bm);
+        if (e == hipSuccess) e = up(o_C, Cm);
+        if (e == hipSuccess) e = up(o_D, D);
+        if (e == hipSuccess) e = up(o_bias, bias);
+        if (e != hipSuccess) break;
+        p.u = dev + o_u; p.delta = dev + o_dl; p.A = dev + o_A; p.B = dev + o_B; p.C = dev + o_C; p.D = dev + o_D; p.delta_bias = dev + o_bias;
+        p.out = dev + o_out; p.x = dev + o_x;
+        q.dout = dev + o_g; q.du = dev + o_du; q.ddelta = dev + o_dd; q.dA = dev + o_dA; q.dB = dev + o_dB; q.dC = dev + o_dC;
+        q.dD = dev + o_dD; q.ddelta_bias = dev + o_db;
+        const int64_t wf = sigma_scan_fwd_workspace_bytes(&p), wb = sigma_scan_bwd_workspace_bytes(&q);
+        if (wf < 0 || wb < 0) { rc = SIGMA_ERR_BAD_SHAPE; break; }
+        if (wf > 0) { e = hipMalloc(&ws_f, (size_t)wf); if (e != hipSuccess) break; p.workspace = ws_f; p.workspace_bytes = wf; }
+        rc = sigma_selective_scan_fwd(&p, stream);
+        if (rc != SIGMA_OK) break;
+        if (wb > 0) { e = hipMalloc(&ws_b, (size_t)wb); if (e != hipSuccess) break; q.workspace = ws_b; q.workspace_bytes = wb; }
+        rc = sigma_selective_scan_bwd(&q, stream);
+        if (rc != SIGMA_OK) break;
+        e = down(h_out, o_out);
+        if (e == hipSuccess) e = down(h_du, o_du);
+        if (e == hipSuccess) e = down(h_dd, o_dd);
+        if (e == hipSuccess) e = down(h_dA, o_dA);
+        if (e == hipSuccess) e = down(h_dB, o_dB);
+        if (e == hipSuccess) e = down(h_dC, o_dC);
+        if (e == hipSuccess) e = down(h_dD, o_dD);
+        if (e == hipSuccess) e = down(h_db, o_db);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+    } while (false);
+    (void)hipStreamSynchronize(s);
+    (void)hipFree(dev); (void)hipFree(ws_f); (void)hipFree(ws_b);
+    if (e != hipSuccess) return fail(SIGMA_ERR_LAUNCH, "row-lane selftest failed to run: %s", hipGetErrorString(e));
+    if (rc != SIGMA_OK) return rc;                                    // sigma_scan_last_error() holds the entry point's message
+    auto worst = [](const std::vector<float>& got, const std::vector<double>& want) {
+        double mx = 0.0, err = 0.0;
+        for (size_t i = 0; i < got.size(); ++i) {
+            mx = std::fmax(mx, std::fabs(want[i]));
+            const double d = std::fabs((double)got[i] - want[i]);
+            err = (d == d) ? std::fmax(err, d) : 1e30;               // NaN counts as a failure
+        }
+        return err / (mx + 1.0);
+    };
+    const double errs[8] = {worst(h_out, r_out), worst(h_du, r_du), worst(h_dd, r_dd), worst(h_dA, r_dA),
+                            worst(h_dB, r_dB), worst(h_dC, r_dC), worst(h_dD, r_dD), worst(h_db, r_db)};
+    for (int i = 0; i < 8; ++i)
+        if (!(errs[i] < 2e-4))
+            return fail(SIGMA_ERR_LAUNCH, "row-lane selftest mismatch (scaled max errors): out=%g du=%g ddelta=%g dA=%g dB=%g dC=%g dD=%g dbias=%g",
+                        errs[0], errs[1], errs[2], errs[3], errs[4], errs[5], errs[6], errs[7]);
     return SIGMA_OK;
 }
 

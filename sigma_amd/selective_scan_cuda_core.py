@@ -187,6 +187,29 @@ def fwd(u: torch.Tensor, delta: torch.Tensor, A: torch.Tensor, B: torch.Tensor, 
     return fwd_ext(u, delta, A, B, C, D_, delta_bias_, delta_softplus, nrows=nrows)
 
 
+_ROWLANE_TESTED = set()
+
+
+def rowlane_selftest(device=None) -> None:
+    """Once per process and device, before the first ckpt_pitch-16 launch: ``sigma_scan_rowlane_selftest`` (include/sigma_scan.h)
+    runs the row-lane kernels on a small problem and compares forward + seven gradients with a host recurrence -- their
+    memory waits are hand-counted, so a toolchain that schedules them differently must fail here, loudly.
+    Allocates and synchronises: never inside a stream capture (graphed steps call this before they capture)."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    key = dev.index if dev.index is not None else torch.cuda.current_device()
+    if key in _ROWLANE_TESTED:
+        return
+    if torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("sigma_amd: the first row-lane scan of this process on this device was issued inside a stream "
+                           "capture; run one step (or selective_scan_cuda_core.rowlane_selftest(device)) eagerly first")
+    with torch.cuda.device(dev):
+        rc = _capi.load().sigma_scan_rowlane_selftest(ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    if rc != 0:
+        raise RuntimeError(f"sigma_scan_rowlane_selftest failed on {dev} (status {rc}): {_capi.last_error()} -- rebuild "
+                           f"libsigma_hip.so with the supported ROCm toolchain")
+    _ROWLANE_TESTED.add(key)
+
+
 def fwd_ext(u, delta, A, B, C, D_, delta_bias_, delta_softplus, nrows: int = 1, rev_mask: int = 0,
             u_gshift: int = 0, need_x: bool = True, fine_ckpt: bool = False, ckpt_pitch: int = 0,
             param_swap: int = 0) -> List[torch.Tensor]:
@@ -221,6 +244,7 @@ def fwd_ext(u, delta, A, B, C, D_, delta_bias_, delta_softplus, nrows: int = 1, 
               rev_mask, u_gshift, ckpt_pitch, param_swap)
     workspace = None
     if ckpt_pitch == _capi.SIGMA_SCAN_CKPT_PITCH_16:                # few rows: forward summaries of the sequence segments
+        rowlane_selftest(u.device)
         ws_bytes = int(lib.sigma_scan_fwd_workspace_bytes(ctypes.byref(fp)))
         _check(ws_bytes >= 0, "selective_scan_fwd: " + _capi.last_error())
         if ws_bytes > 0:

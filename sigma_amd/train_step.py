@@ -154,8 +154,10 @@ def make_graphed_step(net: nn.Module, opt, batch: Tuple[torch.Tensor, ...], warm
     static = tuple(t.clone() for t in batch)
     _tensor_lrs(opt)
     from .gemm import gemm_mode, selftest
+    from .selective_scan_cuda_core import rowlane_selftest
     if gemm_mode() == "split3":
         selftest(static[0].device)                           # not inside the capture (warmup=0)
+    rowlane_selftest(static[0].device)
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):                            # warm-up off the capture stream: lazy inits, LDS caps
@@ -239,8 +241,10 @@ def make_graphed_ddp_step(model: nn.Module, opt, batch: Tuple[torch.Tensor, ...]
     flat = flatten_grads(model)
     _tensor_lrs(opt)
     from .gemm import gemm_mode, selftest
+    from .selective_scan_cuda_core import rowlane_selftest
     if gemm_mode() == "split3":
         selftest(static[0].device)
+    rowlane_selftest(static[0].device)
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):

@@ -74,6 +74,24 @@ def test_native_library_and_wave_primitives():
     assert rc == 0, _capi.last_error()
 
 
+@pytest.mark.parametrize("opts", [{}, {"rl_segs": 1}, {"rl_segs": 2}, {"rl_waves": 8}], ids=["auto", "one-segment", "two-segments", "8-fwd-waves"])
+def test_row_lane_load_time_self_test(opts):
+    """sigma_scan_rowlane_selftest (include/sigma_scan.h, ABI 9): the row-lane kernels against a host recurrence in
+    double precision on a small problem, under the planner's choice and with the segment / wave geometry forced; the
+    binding runs it once per device before the first ckpt_pitch-16 launch (selective_scan_cuda_core.rowlane_selftest)."""
+    from sigma_amd import _capi
+    lib = _capi.load()
+    try:
+        for k, v in opts.items():
+            _capi.set_option(k, v)
+        rc = lib.sigma_scan_rowlane_selftest(None)
+        assert rc == 0, _capi.last_error()
+    finally:
+        for k in opts:
+            _capi.set_option(k, 0)
+    _core().rowlane_selftest("cuda:0")                    # idempotent
+
+
 def _load_golden(path):
     z = np.load(path, allow_pickle=False)
     meta = ast.literal_eval(str(z["meta"]))
