@@ -6,6 +6,7 @@
 #   trace <tag> [bench.py args]    rocprofv3 --kernel-trace --stats of a short bench run, summarised by tools/prof_summary.py
 #   pmc <tag> <shape> [scan_bench args]   FETCH_SIZE / WRITE_SIZE passes of one scan launch shape (tools/gpu_pmc.sh)
 #   scanbench <tag> <shapes> [lib suffixes...]   tools/scan_bench.py on the shapes, once per library variant ("" = the product build)
+#   extras [tag]         forward-only lines, sigma_base 720x1280, batch-8 HIP graph, step without the TunableOp table
 #   final [n]            end-of-round evidence on the final code: driver x n, bench, trace, pmc of the dominant launch
 set -u
 step=${1:-driver}
@@ -83,6 +84,15 @@ final)
   # the driver's N-rank launch line with one rank (RCCL process group, DDP wrapper): train.py:107,168
   ( timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline ) > $out/bench_torchrun_one_rank.log 2>&1; grep "^{" $out/bench_torchrun_one_rank.log | cut -c1-300
   ( timeout 600 python bench.py --per-gpu-batch 1 --graph --no-cpu-baseline ) > $out/bench_b1_graph.log 2>&1; grep "^{" $out/bench_b1_graph.log | cut -c1-200
+  ;;
+extras)
+  # measurements beside the headline: forward only (BASELINE configs[1]), sigma_base 720x1280 (configs[4]), the batch-8 step as a
+  # HIP graph, and the step without the TunableOp table for the vendor GEMMs
+  out=gpurun_out/${1:-extras}; mkdir -p $out
+  ( timeout 600 python tools/eval_bench.py; timeout 600 python tools/eval_bench.py --backbone sigma_small --batch 8 --classes 40 ) > $out/eval_fwd.log 2>&1; grep "^{" $out/eval_fwd.log | cut -c1-300
+  ( timeout 600 python bench.py --backbone sigma_base --height 720 --width 1280 --classes 5 --per-gpu-batch 1 --no-cpu-baseline ) > $out/bench_config5.log 2>&1; grep "^{" $out/bench_config5.log | cut -c1-200
+  ( timeout 600 python bench.py --graph --no-cpu-baseline ) > $out/bench_b8_graph.log 2>&1; grep "^{" $out/bench_b8_graph.log | cut -c1-200
+  ( SIGMA_TUNED_GEMMS=0 timeout 600 python bench.py --no-cpu-baseline ) > $out/bench_b8_untuned.log 2>&1; grep "^{" $out/bench_b8_untuned.log | cut -c1-200
   ;;
 *)
   echo "unknown step $step"; exit 2
