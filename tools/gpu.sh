@@ -81,7 +81,7 @@ final)
   bench $out --steps 20 --warmup 5
   trace $out
   SCAN_BENCH_ARGS="" bash tools/gpu_pmc.sh final/pmc enc_s2_b16 traffic > $out/pmc.txt 2>&1; grep -A3 "^== " $out/pmc.txt | grep -v "^--" | cut -c1-300
-  # the driver's N-rank launch line with one rank (RCCL process group, DDP wrapper): train.py:107,168
+  # the driver's N-rank launch line with one rank (launch plumbing; bench.py builds a process group only for world > 1 or --force-ddp): train.py:107,168
   ( timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline ) > $out/bench_torchrun_one_rank.log 2>&1; grep "^{" $out/bench_torchrun_one_rank.log | cut -c1-300
   ( timeout 600 python bench.py --per-gpu-batch 1 --graph --no-cpu-baseline ) > $out/bench_b1_graph.log 2>&1; grep "^{" $out/bench_b1_graph.log | cut -c1-200
   ;;
