@@ -144,8 +144,8 @@ __device__ __forceinline__ v4f rl_load4u(const float* __restrict__ row, int off,
     const v4f z = {0.0f, 0.0f, 0.0f, 0.0f};
 #if SIGMA_RL_ABL & 4
     const float c = 0.001f * (float)((reinterpret_cast<uintptr_t>(row) + off) & 0xff);
-    const v4f t = {c, 0.5f * c, 0.25f * c, -c};
-    return ok ? t : z;
+    const v4f tc = {c, 0.5f * c, 0.25f * c, -c};
+    return ok ? tc : z;
 #endif
     const v4f t = *reinterpret_cast<const v4f*>(row + (ok ? off : 0));
     return ok ? t : z;
@@ -225,7 +225,12 @@ __device__ __forceinline__ void scan_bwdr_body(const BwdArgs& q, float* smem, co
     const int B_ns = (int)p.B_ns, C_ns = (int)p.C_ns;               // host: (N - 1) * stride + L fits 31 bits
     const long rowblock = (long)b * (p.dim >> 6) + (row0 >> 6);
     // checkpoints: x[((rowblock * ntiles + tile) * 2 + h) * N + n) * 64 + lane], h = 0 after the first scan half of the tile
+#if SIGMA_BWDR_FULL
+    // checkpoints (one per tile): x[((rowblock * ntiles + tile) * N + n) * 64 + lane] = state after memory tile `tile` in scan order
+    const float* ck = p.x + rowblock * ntiles * N * 64 + (long)n0 * 64;         // wave-uniform; + lane at the use
+#else
     const float* ck = p.x + rowblock * ntiles * 2 * N * 64 + (long)n0 * 64;     // wave-uniform; + lane at the use
+#endif
 
     // dB / dC of this row block: the caller's tensors when the block is the whole group, else its slab of the workspace
     float* __restrict__ oB;
@@ -296,8 +301,14 @@ __device__ __forceinline__ void scan_bwdr_body(const BwdArgs& q, float* smem, co
 #if SIGMA_RL_ABL & 2
         return 0.001f * st;
 #endif
+#if SIGMA_BWDR_FULL
+        (void)hs;
+        const int tl = tile_of(st > 0 ? st - 1 : 0);                // state entering scan step st = after the previous step's tile
+        return ck[(unsigned)((tl * N + s) * 64 + lane)];
+#else
         const int tl = hs == 1 ? tile_of(st) : tile_of(st > 0 ? st - 1 : 0);
         return ck[(unsigned)(((tl * 2 + (hs == 1 ? 0 : 1)) * N + s) * 64 + lane)];      // host: floats per row block < 2^31
+#endif
     };
 
     // u / delta / dout of a tile travel by LDS-DMA one tile ahead (with register targets the compiler, short of
@@ -318,7 +329,7 @@ __device__ __forceinline__ void scan_bwdr_body(const BwdArgs& q, float* smem, co
     v4f d_nx = rl_load4u(d_blk + d_off - 4 * cc, T * m + 4 * cc, T * m + 4 * cc < L);
     v4f g_nx = rl_load4u(g_blk + g_off - 4 * cc, T * m + 4 * cc, T * m + 4 * cc < L);
 #endif
-    float x1_nx[NS];                                                // entering the second scan half of the next step
+    float x1_nx[NS];                                                // entering the second scan half of the next step (FULL: entering the next step)
 #pragma unroll
     for (int s = 0; s < NS; ++s) x1_nx[s] = ck_in(st, 1, s);
     // B / C of the NEXT tile are pulled into L2 a tile ahead (see scan_fwdr.hip)
@@ -333,9 +344,16 @@ __device__ __forceinline__ void scan_bwdr_body(const BwdArgs& q, float* smem, co
         const bool valid = !TAIL || T * m + 4 * cc < L;
         const int nch = TAIL ? (L - T * m) >> 2 : 4;                // valid 16-byte chunks of this tile
         const int hm_first = REV ? 0 : 1;                           // memory half of the second scan half (walked first)
+#if SIGMA_BWDR_FULL
+        (void)hm_first;
+        float Bn[T], Cn[T];
+        rl_load_bc(Bw + T * m, nch, Bn);                            // first state's B / C: requested before anything waits
+        rl_load_bc(Cw + T * m, nch, Cn);
+#else
         float Bn[H], Cn[H];
         rl_load_bc8(Bw + T * m + H * hm_first, nch - 2 * hm_first, Bn);      // first step's B / C: requested before anything waits
         rl_load_bc8(Cw + T * m + H * hm_first, nch - 2 * hm_first, Cn);
+#endif
         __builtin_amdgcn_sched_barrier(0);
 #if SIGMA_RL_DMA
         // This tile's u / delta / dout have landed.  A full step of the loop issues 3 + 2 NS vector-memory operations
@@ -353,8 +371,13 @@ __device__ __forceinline__ void scan_bwdr_body(const BwdArgs& q, float* smem, co
         float x1[NS], x0[NS];
         const float x0_scale = st > 0 ? 1.0f : 0.0f;
         touch_acc += touch_nx;
+#if SIGMA_BWDR_FULL
+#pragma unroll
+        for (int s = 0; s < NS; ++s) { x1[s] = x1_nx[s]; x0[s] = 0.0f; }               // x1: the state entering this tile
+#else
 #pragma unroll
         for (int s = 0; s < NS; ++s) { x1[s] = x1_nx[s]; x0[s] = ck_in(st, 0, s); }     // x0: used half a tile from now
+#endif
         {                                                           // next tile's operands fly during this tile
             const bool more = it + 1 < nst;
             const int mn = tile_of(more ? st - 1 : st);
@@ -399,6 +422,109 @@ __device__ __forceinline__ void scan_bwdr_body(const BwdArgs& q, float* smem, co
         rl_barrier();
         RLPROF(1)                                                   // barrier 1
 
+#if SIGMA_BWDR_FULL
+        {
+            float dl[T], dlu[T], gg[T], sdxB[T], sAx[T];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const v4f a4 = sProc[rl_unit(c, lane)], b4 = sProc[256 + rl_unit(c, lane)], g4r = sProc[512 + rl_unit(c, lane)];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    dl[4 * c + j] = a4[j]; dlu[4 * c + j] = b4[j]; gg[4 * c + j] = g4r[j];
+                    sdxB[4 * c + j] = 0.0f; sAx[4 * c + j] = 0.0f;
+                }
+            }
+            // LDS reads and scalar loads share one counter: retire the reads before the first scalar request of the state loop
+            asm volatile("" : "+v"(dl[0]), "+v"(dlu[0]), "+v"(gg[0]), "+v"(dl[4]), "+v"(dlu[4]), "+v"(gg[4]),
+                              "+v"(dl[8]), "+v"(dlu[8]), "+v"(gg[8]), "+v"(dl[12]), "+v"(dlu[12]), "+v"(gg[12]));
+            __builtin_amdgcn_sched_barrier(0);
+            RLPROF(2)                                               // LDS reads
+            const float xin_scale = st > 0 ? 1.0f : 0.0f;
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                float Bt[T], Ct[T];
+#pragma unroll
+                for (int k = 0; k < T; ++k) { Bt[k] = Bn[k]; Ct[k] = Cn[k]; }
+                // scalar loads return out of order: wait for THIS state's operands (lgkmcnt(0)), then request the next state's
+                asm volatile("" : "+s"(Bt[0]), "+s"(Ct[0]));
+                __builtin_amdgcn_sched_barrier(0);
+                RLPROF(3)                                           // scalar operand wait
+                if (s + 1 < NS) {
+                    rl_load_bc(Bw + (s + 1) * B_ns + T * m, nch, Bn);
+                    rl_load_bc(Cw + (s + 1) * C_ns + T * m, nch, Cn);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                const float xin = x1[s] * xin_scale;
+                float a[T], xs[T];
+                // ---- forward replay of the tile from the state entering it
+                {
+                    float x = xin;
+#pragma unroll
+                    for (int kk = 0; kk < T; ++kk) {
+                        const int k = REV ? T - 1 - kk : kk;
+                        a[k] = fast_exp2(dl[k] * A2[s]);
+                        x = fmaf(a[k], x, dlu[k] * Bt[k]);
+                        xs[k] = x;
+                    }
+                }
+                // ---- reverse: dx_k = g_k C_k + e_{k+1}, e_k = a_k dx_k
+                float e = ecar[s];
+                float w[H], ph_first = 0.0f;
+#pragma unroll
+                for (int kk = T - 1; kk >= 0; --kk) {
+                    const int k = REV ? T - 1 - kk : kk;
+                    const float dx = fmaf(gg[k], Ct[k], e);
+                    e = a[k] * dx;
+                    const int kp = REV ? k + 1 : k - 1;             // previous position in scan order
+                    const float xprev = kk > 0 ? xs[kk > 0 ? kp : k] : xin;
+                    sdxB[k] = fmaf(dx, Bt[k], sdxB[k]);
+                    const float t = e * xprev;                      // dx * a_k * x_{k-1}
+                    sAx[k] = fmaf(A2[s], t, sAx[k]);                // x ln 2 in the epilogue
+                    dAacc[s] = fmaf(dl[k], t, dAacc[s]);
+#if SIGMA_RL_ABL & 64
+                    w[k & 7] = dx * dlu[k] + gg[k] * xs[k];
+#else
+                    w[k & 7] = rl_fold32(dx * dlu[k], gg[k] * xs[k]);  // this row's terms of dB[n, l] and dC[n, l], wave halves summed
+#endif
+                    if (kk == H) {                                  // the half walked first is complete: memory half REV ? 0 : 1
+#if SIGMA_RL_ABL & 64
+                        ph_first = ((w[0] + w[1]) + (w[2] + w[3])) + ((w[4] + w[5]) + (w[6] + w[7]));
+#else
+                        ph_first = rl_reduce_half(w);
+#endif
+                    }
+                }
+                ecar[s] = e;
+#if SIGMA_RL_ABL & 64
+                const float tot = ph_first + (((w[0] + w[1]) + (w[2] + w[3])) + ((w[4] + w[5]) + (w[6] + w[7])));
+#else
+                const float ph_second = rl_reduce_half(w);          // memory half REV ? 1 : 0
+                const float tot = REV ? rl_reduce_finish(ph_first, ph_second) : rl_reduce_finish(ph_second, ph_first);
+#endif
+                if (!TAIL || T * m + o_pos < L) o_lane[s * o_ns_lane + T * m] = tot;
+                __builtin_amdgcn_sched_barrier(0);
+                RLPROF(4)                                           // state loop
+            }
+            // ---- the sums over the states of the four waves meet in LDS
+#if SIGMA_RL_ABL & 16
+            asm volatile("" :: "v"(sdxB[0]), "v"(sdxB[5]), "v"(sAx[2]), "v"(sAx[7]), "v"(sdxB[9]), "v"(sAx[14]));
+#else
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const v4f t1 = {sdxB[4 * c], sdxB[4 * c + 1], sdxB[4 * c + 2], sdxB[4 * c + 3]};
+                const v4f t2 = {sAx[4 * c], sAx[4 * c + 1], sAx[4 * c + 2], sAx[4 * c + 3]};
+                sEx[(sw * 2) * 256 + rl_unit(c, lane)] = t1;
+                sEx[(sw * 2 + 1) * 256 + rl_unit(c, lane)] = t2;
+            }
+#endif
+            {                                                       // the state entering the NEXT step
+                const int stn = it + 1 < nst ? st - 1 : st;
+#pragma unroll
+                for (int s = 0; s < NS; ++s) x1_nx[s] = ck_in(stn, 1, s);
+            }
+            RLPROF(5)                                               // exchange writes
+        }
+#else
 #if SIGMA_RL_MFMA
         float psB[NS], psC[NS];                                     // 4-lane sums of the half walked first, per state
 #else
@@ -549,6 +675,7 @@ __device__ __forceinline__ void scan_bwdr_body(const BwdArgs& q, float* smem, co
             }
             RLPROF(5)                                               // exchange writes
         }
+#endif
         rl_barrier();
         RLPROF(6)                                                   // barrier 2
         {

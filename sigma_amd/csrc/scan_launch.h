@@ -53,7 +53,15 @@ inline size_t fwd4_lds_bytes(int N) { return sizeof(float) * (2 * 2 * (size_t)N 
 
 // row-lane kernels (scan_fwdr.hip / scan_bwdr.hip): [arrays][4 chunks][64 rows] float4 of pre-processed operands +
 // [state waves][...] partial sums over the states
-inline size_t fwdr_lds_bytes(int NW) { return 16 * (size_t)(2 * 256 + NW * 256); }
+// round 6 (SIGMA_FWDR_PIPE): four state waves run the pipelined body on double-buffered blocks (48 KB: three workgroups per CU)
+#ifndef SIGMA_FWDR_PIPE
+#define SIGMA_FWDR_PIPE 1
+#endif
+// tiles the (row, chunk) loads of u / delta run ahead of the state loop (1 or 2)
+#ifndef SIGMA_FWDR_PF
+#define SIGMA_FWDR_PF 1
+#endif
+inline size_t fwdr_lds_bytes(int NW) { return SIGMA_FWDR_PIPE && NW == 4 ? 16 * (size_t)(4 * 256 + 2 * 4 * 256) : 16 * (size_t)(2 * 256 + NW * 256); }
 #if defined(SIGMA_RL_ABL) && (SIGMA_RL_ABL & 128)
 inline size_t bwdr_lds_bytes(int NW) { return 16 * (size_t)(5 * 256 + NW * 256 + 3 * 256); }        // timing probe: half the exchange area
 #else

@@ -39,6 +39,17 @@
 #define SIGMA_RL_ABL 0
 #endif
 
+// Round 6: 1 = ONE checkpoint per tile -- the state after the tile, x[((rowblock * ntiles + tile) * N + n) * 64 + lane] -- so
+// the forward writes half as many checkpoint bytes (it is bound by HBM traffic: 0.5 of its 1.3 GB per launch were
+// checkpoints) and the backward reads half as many, walking the tile WHOLE: per state a forward replay of its 16 positions
+// from the state entering the tile, then the reverse recurrence over the 16 positions.  Same arithmetic per element-state as
+// the half-tile walk (every position is replayed exactly once either way), 16-entry per-lane arrays (~250 VGPRs: the two
+// waves per SIMD this kernel runs with have them), B / C of a (state, tile) in ONE 16-dword scalar request each.
+// 0: the round-4 scheme (two checkpoints per tile, the backward in halves of 8 positions).
+#ifndef SIGMA_BWDR_FULL
+#define SIGMA_BWDR_FULL 1
+#endif
+
 namespace sigma {
 namespace {
 

@@ -117,6 +117,8 @@ def main():
     ap.add_argument("--opt", action="append", default=[], help="library option name=value (sigma_scan_set_option), repeatable")
     ap.add_argument("--pitch", type=int, default=0, help="force this checkpoint pitch (with --fine): 16 = row-lane kernels, 160 = quad-row")
     a = ap.parse_args()
+    if os.environ.get("SIGMA_BENCH_NO_SELFTEST"):       # timing-only ablation builds (wrong results by construction)
+        core._ROWLANE_TESTED.update(range(16))
     for kv in a.opt:
         k, v = kv.split("=")
         _capi.set_option(k, int(v))
