@@ -74,10 +74,11 @@ enum sigma_status {
  * Pitch 16 selects the row-lane kernels (scan_fwdr.hip / scan_bwdr.hip: a lane = a channel row, a wave = 64 rows x a
  * quarter / an eighth of the states, B and C as scalar operands): f32 IO, dstate in {4, 8, 16}, rows per group divisible
  * by 64, seqlen % 4 == 0, 16-byte aligned operands; BOTH entry points fail with SIGMA_ERR_BAD_SHAPE otherwise.  x then
- * holds 2 * ceil(seqlen / 16) * dstate floats per row (one checkpoint per 8 positions; the backward walks its 16-position
- * tiles as two halves) in a layout private to the two kernels (x_row_stride is ignored):
- *     x[((((b * dim/64 + r/64) * ceil(L/16) + tile) * 2 + h) * N + n) * 64 + r % 64] = state n of row r after the first
- *     half (h = 0, scan order) / after the whole (h = 1) of memory tile `tile`.
+ * holds ceil(seqlen / 16) * dstate floats per row (one checkpoint per 16-position tile: the backward replays a tile whole
+ * from the state entering it; rounds 4-5 kept two per tile and walked halves -- the forward is bound by its HBM traffic, of
+ * which those checkpoints were 40 %) in a layout private to the two kernels (x_row_stride is ignored):
+ *     x[((b * dim/64 + r/64) * ceil(L/16) + tile) * N * 64 + ((n / G) * 64 + r % 64) * G + n % G], G = N / 4, = state n
+ *     of row r after memory tile `tile` in scan order (a reversed group walks the tiles downwards).
  * With few rows both kernels cut the sequence into segments run by different workgroups (a pre-pass writes per-segment
  * summaries into the workspace): see sigma_scan_fwd_workspace_bytes / sigma_scan_bwd_workspace_bytes. */
 #define SIGMA_SCAN_CHUNK 2048

@@ -929,7 +929,7 @@ int sigma_scan_selftest(void* stream) {
 int sigma_scan_rowlane_selftest(void* stream) {
     hipStream_t s = static_cast<hipStream_t>(stream);
     const int Bt = 1, G = 2, RPG = 64, KD = G * RPG, L = 148, N = 16, NT = (L + 15) / 16;
-    const size_t nrow = (size_t)KD * L, nbc = (size_t)G * N * L, nx = (size_t)KD * 2 * NT * N;
+    const size_t nrow = (size_t)KD * L, nbc = (size_t)G * N * L, nx = (size_t)KD * NT * N;
     std::vector<float> u(nrow), dl(nrow), g(nrow), A((size_t)KD * N), Bm(nbc), Cm(nbc), D(KD), bias(KD);
     unsigned st = 2463534242u;
     auto rnd = [&]() { st = st * 1664525u + 1013904223u; return (float)((st >> 8) & 0xffff) / 32768.0f - 1.0f; };   // [-1, 1)

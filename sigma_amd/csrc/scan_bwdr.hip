@@ -227,7 +227,7 @@ __device__ __forceinline__ void scan_bwdr_body(const BwdArgs& q, float* smem, co
     // checkpoints: x[((rowblock * ntiles + tile) * 2 + h) * N + n) * 64 + lane], h = 0 after the first scan half of the tile
 #if SIGMA_BWDR_FULL
     // checkpoints (one per tile): x[((rowblock * ntiles + tile) * N + n) * 64 + lane] = state after memory tile `tile` in scan order
-    const float* ck = p.x + rowblock * ntiles * N * 64 + (long)n0 * 64;         // wave-uniform; + lane at the use
+    const float* ck = p.x + rowblock * ntiles * N * 64;                         // wave-uniform; rl_load_ck adds the wave's slot
 #else
     const float* ck = p.x + rowblock * ntiles * 2 * N * 64 + (long)n0 * 64;     // wave-uniform; + lane at the use
 #endif
@@ -297,14 +297,13 @@ __device__ __forceinline__ void scan_bwdr_body(const BwdArgs& q, float* smem, co
     // state entering scan half hs of scan step st: after the first half of the same tile / after the previous tile
     // (before the first scan step there is no checkpoint: the load is clamped to a valid one and the caller scales by zero
     // at the point of USE -- a select next to the load would make the compiler wait for it there)
-    auto ck_in = [&](int st, int hs, int s) {
+    [[maybe_unused]] auto ck_in = [&](int st, int hs, int s) {
 #if SIGMA_RL_ABL & 2
         return 0.001f * st;
 #endif
 #if SIGMA_BWDR_FULL
-        (void)hs;
-        const int tl = tile_of(st > 0 ? st - 1 : 0);                // state entering scan step st = after the previous step's tile
-        return ck[(unsigned)((tl * N + s) * 64 + lane)];
+        (void)hs; (void)s;
+        return 0.0f;                                                // (the whole-tile walk loads its NS states at once: ck_load)
 #else
         const int tl = hs == 1 ? tile_of(st) : tile_of(st > 0 ? st - 1 : 0);
         return ck[(unsigned)(((tl * 2 + (hs == 1 ? 0 : 1)) * N + s) * 64 + lane)];      // host: floats per row block < 2^31
@@ -330,8 +329,21 @@ __device__ __forceinline__ void scan_bwdr_body(const BwdArgs& q, float* smem, co
     v4f g_nx = rl_load4u(g_blk + g_off - 4 * cc, T * m + 4 * cc, T * m + 4 * cc < L);
 #endif
     float x1_nx[NS];                                                // entering the second scan half of the next step (FULL: entering the next step)
+#if SIGMA_BWDR_FULL
+    // the NS states entering scan step st_ = those after the previous step's tile: one access per lane (before the first
+    // step there is none: the load is clamped to a valid block and the value scaled by zero where it is used)
+    auto ck_load = [&](int st_, float (&xo)[NS]) {
+#if SIGMA_RL_ABL & 2
+        for (int s = 0; s < NS; ++s) xo[s] = 0.001f * st_;
+        return;
+#endif
+        rl_load_ck<NS, NS>(ck + (unsigned)(tile_of(st_ > 0 ? st_ - 1 : 0) * N * 64), n0, lane, xo);      // host: floats per row block < 2^31
+    };
+    ck_load(st, x1_nx);
+#else
 #pragma unroll
     for (int s = 0; s < NS; ++s) x1_nx[s] = ck_in(st, 1, s);
+#endif
     // B / C of the NEXT tile are pulled into L2 a tile ahead (see scan_fwdr.hip)
     const float* __restrict__ bc_touch = ((lane & 1) ? Cw : Bw) + (long)((lane >> 1) & (NS - 1)) * ((lane & 1) ? C_ns : B_ns);
     float touch_nx = 0.0f, touch_acc = 0.0f;
@@ -359,7 +371,8 @@ __device__ __forceinline__ void scan_bwdr_body(const BwdArgs& q, float* smem, co
         // This tile's u / delta / dout have landed.  A full step of the loop issues 3 + 2 NS vector-memory operations
         // after its requests (the touch, NS checkpoint loads, NS dB/dC stores, du, ddelta), which stay in
         // flight; the partial tile may skip some of them, so it (and the step after it: the caller waits) drains the counter.
-        if (TAIL) rl_dma_wait(); else rl_dma_wait_keep<3 + 2 * NS>();
+        // (whole-tile walk: the touch, ONE checkpoint load, NS dB/dC stores, du, ddelta)
+        if (TAIL) rl_dma_wait(); else rl_dma_wait_keep<SIGMA_BWDR_FULL ? 4 + NS : 3 + 2 * NS>();
         RLPROF(8)                                                   // wait for this tile's u / delta / dout (LDS-DMA)
         const v4f uu = sRaw[tid], dd = sRaw[256 + tid];
         v4f g4 = sRaw[512 + tid];
@@ -369,7 +382,7 @@ __device__ __forceinline__ void scan_bwdr_body(const BwdArgs& q, float* smem, co
         const v4f uu = u_nx, dd = d_nx, g4 = g_nx;
 #endif
         float x1[NS], x0[NS];
-        const float x0_scale = st > 0 ? 1.0f : 0.0f;
+        const float x0_scale = st > 0 ? 1.0f : 0.0f; (void)x0_scale;
         touch_acc += touch_nx;
 #if SIGMA_BWDR_FULL
 #pragma unroll
@@ -517,11 +530,7 @@ __device__ __forceinline__ void scan_bwdr_body(const BwdArgs& q, float* smem, co
                 sEx[(sw * 2 + 1) * 256 + rl_unit(c, lane)] = t2;
             }
 #endif
-            {                                                       // the state entering the NEXT step
-                const int stn = it + 1 < nst ? st - 1 : st;
-#pragma unroll
-                for (int s = 0; s < NS; ++s) x1_nx[s] = ck_in(stn, 1, s);
-            }
+            ck_load(it + 1 < nst ? st - 1 : st, x1_nx);              // the states entering the NEXT step
             RLPROF(5)                                               // exchange writes
         }
 #else

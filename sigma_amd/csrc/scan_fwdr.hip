@@ -215,15 +215,16 @@ __device__ __forceinline__ void scan_fwdr_body(const FwdArgs& p, float* smem, in
             xst[s] = x;
             if (SUMMARY) Pacc[s] = fmaf(dsum, A2[s], Pacc[s]);
 #if !(SIGMA_RL_ABL & 2)
-#if SIGMA_BWDR_FULL
-            if (CK) ck[((long)m * N + n0 + s) * 64] = x;            // state after memory tile m (scan order)
-#else
+#if !SIGMA_BWDR_FULL
             if (CK) ck[((long)(m * 2 + 1) * N + n0 + s) * 64] = x;  // state after memory tile m (scan order)
 #endif
 #endif
             __builtin_amdgcn_sched_barrier(0);
             RLPROF(4)                                               // state loop
         }
+#if SIGMA_BWDR_FULL && !(SIGMA_RL_ABL & 2)
+        if (CK) rl_store_ck<NS, NS * NW / 4>(ck - lane + (long)m * N * 64, n0, lane, xst);     // the states after memory tile m (scan order)
+#endif
 #if SIGMA_RL_ABL & 16
         asm volatile("" :: "v"(y[0]), "v"(y[5]), "v"(y[10]), "v"(y[15]));
 #else
@@ -317,7 +318,7 @@ __device__ __forceinline__ void scan_fwdp_body(const FwdArgs& p, float* smem, in
     const int B_ns = (int)p.B_ns, C_ns = (int)p.C_ns;               // host: (N - 1) * stride + L fits 31 bits
     const long rowblock = (long)b * (p.dim >> 6) + (row0 >> 6);
 #if SIGMA_BWDR_FULL
-    float* __restrict__ ck = CK ? p.x + rowblock * ntiles * N * 64 + (long)n0 * 64 + lane : nullptr;      // one checkpoint per tile
+    float* __restrict__ ck = CK ? p.x + rowblock * ntiles * N * 64 : nullptr;      // one checkpoint block per tile (rl_store_ck)
 #else
     float* __restrict__ ck = CK ? p.x + rowblock * ntiles * 2 * N * 64 + (long)n0 * 64 + lane : nullptr;
 #endif
@@ -488,9 +489,7 @@ __device__ __forceinline__ void scan_fwdp_body(const FwdArgs& p, float* smem, in
             }
             xst[s] = x;
 #if !(SIGMA_RL_ABL & 2)
-#if SIGMA_BWDR_FULL
-            if (CK) ck[((long)m * N + s) * 64] = x;                 // state after memory tile m (scan order)
-#else
+#if !SIGMA_BWDR_FULL
             if (CK) ck[((long)(m * 2 + 1) * N + s) * 64] = x;       // state after memory tile m (scan order)
 #endif
 #endif
@@ -500,6 +499,9 @@ __device__ __forceinline__ void scan_fwdp_body(const FwdArgs& p, float* smem, in
                               "+v"(y[8]), "+v"(y[9]), "+v"(y[10]), "+v"(y[11]), "+v"(y[12]), "+v"(y[13]), "+v"(y[14]), "+v"(y[15]));
             __builtin_amdgcn_sched_barrier(0);
         }
+#if SIGMA_BWDR_FULL && !(SIGMA_RL_ABL & 2)
+        if (CK) rl_store_ck<NS, NS>(ck + (long)m * N * 64, n0, lane, xst);            // the states after memory tile m (scan order)
+#endif
         RLPROF(4)                                                   // state loop
 #if SIGMA_RL_ABL & 16
         asm volatile("" :: "v"(y[0]), "v"(y[5]), "v"(y[10]), "v"(y[15]));

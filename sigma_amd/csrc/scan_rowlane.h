@@ -39,7 +39,7 @@
 #define SIGMA_RL_ABL 0
 #endif
 
-// Round 6: 1 = ONE checkpoint per tile -- the state after the tile, x[((rowblock * ntiles + tile) * N + n) * 64 + lane] -- so
+// Round 6: 1 = ONE checkpoint per tile -- the state after the tile, a block of N * 64 floats per (row block, tile) (rl_store_ck below) -- so
 // the forward writes half as many checkpoint bytes (it is bound by HBM traffic: 0.5 of its 1.3 GB per launch were
 // checkpoints) and the backward reads half as many, walking the tile WHOLE: per state a forward replay of its 16 positions
 // from the state entering the tile, then the reverse recurrence over the 16 positions.  Same arithmetic per element-state as
@@ -120,6 +120,30 @@ __device__ __forceinline__ void rl_dma_wait() { asm volatile("s_waitcnt vmcnt(0)
 // those left in flight -- so that the wait does not sit out the stores issued just before it
 template <int YOUNGER>
 __device__ __forceinline__ void rl_dma_wait_keep() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(YOUNGER) : "memory"); }
+
+// Checkpoints of one tile (SIGMA_BWDR_FULL): a block of N * 64 floats in which the states go in groups of G = N / 4 (the
+// states of one wave of the backward, which always runs four state waves) and a group is innermost -- slot of state n of
+// lane l = ((n / G) * 64 + l) * G + n % G -- so that the states of a wave are ONE 16- / 8- / 4-byte access per lane and
+// 1 KB / 512 B / 256 B contiguous per wave (a vector-memory instruction costs the issuing SIMD ~25 ns whatever its
+// width: tools/ubench/stateloop_ubench.hip).  n0 = first state of the wave (a multiple of NS); NS in {1, 2, 4}, NS <= G.
+template <int NS, int G>
+__device__ __forceinline__ int rl_ck_slot(int n0, int lane) { return ((n0 / G) * 64 + lane) * G + (n0 % G); }
+template <int NS, int G>
+__device__ __forceinline__ void rl_store_ck(float* __restrict__ tile_block, int n0, int lane, const float (&x)[NS]) {
+    static_assert((NS == 1 || NS == 2 || NS == 4) && NS <= G && G % NS == 0, "states per wave");
+    float* p = tile_block + rl_ck_slot<NS, G>(n0, lane);
+    if constexpr (NS == 4) { const v4f v = {x[0], x[1], x[2], x[3]}; *reinterpret_cast<v4f*>(p) = v; }
+    else if constexpr (NS == 2) { *reinterpret_cast<float2*>(p) = make_float2(x[0], x[1]); }
+    else { p[0] = x[0]; }
+}
+template <int NS, int G>
+__device__ __forceinline__ void rl_load_ck(const float* __restrict__ tile_block, int n0, int lane, float (&x)[NS]) {
+    static_assert((NS == 1 || NS == 2 || NS == 4) && NS <= G && G % NS == 0, "states per wave");
+    const float* p = tile_block + rl_ck_slot<NS, G>(n0, lane);
+    if constexpr (NS == 4) { const v4f v = *reinterpret_cast<const v4f*>(p); x[0] = v[0]; x[1] = v[1]; x[2] = v[2]; x[3] = v[3]; }
+    else if constexpr (NS == 2) { const float2 v = *reinterpret_cast<const float2*>(p); x[0] = v.x; x[1] = v.y; }
+    else { x[0] = p[0]; }
+}
 
 __device__ __forceinline__ void rl_barrier() {
 #if !(SIGMA_RL_ABL & 8)

@@ -130,10 +130,8 @@ _FINE_PITCHES = (_capi.SIGMA_SCAN_CKPT_PITCH_FINE, _capi.SIGMA_SCAN_CKPT_PITCH_3
 
 
 def _ckpt_slots(seqlen: int, pitch: int) -> int:
-    """checkpoints per row of a fine-checkpoint x: one per `pitch` positions; pitch 16 (row-lane kernels): two per
-    16-position tile (include/sigma_scan.h)"""
-    if pitch == _capi.SIGMA_SCAN_CKPT_PITCH_16:
-        return 2 * max((seqlen + 15) // 16, 1)
+    """checkpoints per row of a fine-checkpoint x: one per `pitch` positions (include/sigma_scan.h; the row-lane kernels of
+    pitch 16 kept two per tile in rounds 4-5)"""
     return max((seqlen + pitch - 1) // pitch, 1)
 
 

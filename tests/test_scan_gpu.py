@@ -668,7 +668,7 @@ def _rowlane_run(shape, opts, softplus=True, with_D=True, with_bias=True, seed=2
     finally:
         for k in opts:
             _capi.set_option(k, 0)
-    assert x.shape == (batch, KD, 2 * max((L + 15) // 16, 1) * N)
+    assert x.shape == (batch, KD, max((L + 15) // 16, 1) * N)
     revs = [(mask >> g) & 1 for g in range(G)]
     fr = lambda t: torch.cat([t[:, g * rpg:(g + 1) * rpg].flip(-1) if revs[g] else t[:, g * rpg:(g + 1) * rpg] for g in range(G)], 1)
     fg = lambda t: torch.stack([t[:, g].flip(-1) if revs[g] else t[:, g] for g in range(G)], 1)
