@@ -22,6 +22,7 @@
 //     re-read from that XCD's L2).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/sigma_gemm.h"
 #include "../../include/sigma_ops.h"
@@ -207,6 +208,9 @@ __device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" :
 #ifndef SIGMA_GEMM_DEPTH
 #define SIGMA_GEMM_DEPTH 0
 #endif
+#ifndef SIGMA_GEMM_SLICE_MAJOR
+#define SIGMA_GEMM_SLICE_MAJOR 1           // 0: A/B builds with the tile-major item order for sliced reductions
+#endif
 #ifndef SIGMA_GEMM_ROW_EPILOGUE
 #define SIGMA_GEMM_ROW_EPILOGUE 1          // 0: A/B builds with the direct (dword) epilogue
 #endif
@@ -252,10 +256,19 @@ gemm_split3_kernel(const GemmArgs g) {
         const int lbk = __builtin_amdgcn_readfirstlane(xcd_logical_block(id, total));
         const int z = lbk / per_z;
         const int r0 = lbk - z * per_z;
-        const int tm_i = r0 / (g.ntn * g.slices);
-        const int rem = r0 - tm_i * (g.ntn * g.slices);
-        const int tn_i = rem / g.slices;
-        it.sl = rem - tn_i * g.slices;
+        // reduction slices (weight gradients): the tiles of ONE slice are consecutive (slice-major), so that the workgroups an
+        // XCD runs at the same time stream the same k-range of both operands -- each slice of A and B then comes from HBM once
+        // per XCD instead of once per row / column tile (the tile-major order shares only the A slice among the column
+        // tiles).  One division chain for both orders (selects on wave-uniform values, no branch).
+        const bool slice_major = SIGMA_GEMM_SLICE_MAJOR && A_KS && B_KS && g.slices > 1;
+        const int d1 = slice_major ? g.ntm * g.ntn : g.ntn * g.slices;
+        const int q1 = r0 / d1;
+        const int rem = r0 - q1 * d1;
+        const int d2 = slice_major ? g.ntn : g.slices;
+        const int q2 = rem / d2;
+        const int q3 = rem - q2 * d2;
+        const int tm_i = slice_major ? q2 : q1, tn_i = slice_major ? q3 : q2;
+        it.sl = slice_major ? q1 : q3;
         it.m0 = (long)tm_i * BM;
         it.n0 = tn_i * BN;
         it.kbeg = it.sl * g.slice_k;
@@ -685,7 +698,10 @@ extern "C" int sigma_gemm_tn_split3(const sigma_gemm_params* p, void* stream) {
     const int bn = sigma::pick_bn(g.N);
     const long tiles = (long)batch * ((g.M + 127) / 128) * ((g.N + bn - 1) / bn);
     const long steps = (p->M + 31) / 32;
-    long want = (768 + tiles - 1) / tiles;
+    // ... but no more items than ONE round of resident workgroups (2 per CU): 768 items on 512 slots ran 1.5 rounds and paid
+    // 50 % more atomic tile additions than 504 (round 6: 144 -> 132 us at enc_s2_in_proj, 92 -> 71 us at the small shapes)
+    static const long target_items = [] { const char* e = getenv("SIGMA_GEMM_TN_ITEMS"); const long v = e ? atol(e) : 0; return v > 0 ? v : 512L; }();
+    long want = target_items / tiles;
     if (want > steps / 8) want = steps / 8;
     if (want < 1) want = 1;
     const long per = (steps + want - 1) / want;

@@ -46,6 +46,27 @@ prof)  # phase profile of the row-lane kernels: prof <tag> <shape> <prof-build s
     SIGMA_HIP_LIB=$R/sigma_amd/lib/libsigma_hip$v.so timeout 300 python tools/rowlane_prof.py $shape 2>&1 | grep "^{" | tee -a $out/phases$v.jsonl | cut -c1-600
   done
   ;;
+pitches)  # scan_bench of shapes at several forced pitches: pitches <tag> <shapes> <pitch...>
+  tag=$1; shapes=$2; shift 2; out=gpurun_out/$tag; mkdir -p $out
+  for pp in "$@"; do
+    echo "== pitch $pp"
+    ab $out $shapes "$([ $pp = auto ] && echo '' || echo --pitch $pp)" -
+  done
+  ;;
+gemm)  # gemm_bench A/B: gemm <tag> <only-columns> <variants...>
+  tag=$1; only=$2; shift 2; out=gpurun_out/$tag; mkdir -p $out
+  for v in "$@"; do
+    [ "$v" = "-" ] && v=""
+    echo "== libsigma_hip$v"
+    SIGMA_HIP_LIB=$R/sigma_amd/lib/libsigma_hip$v.so timeout 600 python tools/gemm_bench.py --iters 20 --only $only --out $out/gemm$v.jsonl 2>/dev/null | python -c "
+import sys, json
+for l in sys.stdin:
+    try: r = json.loads(l)
+    except Exception: continue
+    print('%-18s' % r['shape'], ' '.join('%s %7.1f' % (k[:-3], v) for k, v in r.items() if k.endswith('_us')))
+"
+  done 2>&1 | tee -a $out/gemm.txt
+  ;;
 ubench)
   tag=${1:-r6_ubench}; out=gpurun_out/$tag; mkdir -p $out
   timeout 600 tools/ubench/bin/stateloop_ubench | tee $out/stateloop_ubench.jsonl
