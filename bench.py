@@ -302,6 +302,21 @@ def main():
                              avg_us=secs / n * 1e6, algorithmic_MB=by / 1e6, GBs=by / (secs / n) / 1e9))
         rows.sort(key=lambda r: -r["total_ms"])
         scan_ms = sum(r["total_ms"] for r in rows)
+        def valu_floor(kind, shape):
+            """The bound behind the HBM fraction: the S6 recurrence is vector-ALU work.  Element-states of the
+            launch / (64 lanes x 1024 SIMDs) x the issue cost of the arithmetic alone: forward 4 plain + 1 transcendental,
+            backward 12 plain + 1 transcendental + 1 lane swap per element-state.  `nominal`: 2.1 / 8.1 / 8.1 clocks at 2.1
+            GHz (profiles/r03_issue_ubench.jsonl); `measured`: wall-clock cost of the same mix inside a loop at three waves
+            per SIMD (tools/ubench/stateloop_ubench.hip, profiles/r06_stateloop_ubench.jsonl: plain 1.0 ns, v_exp_f32 ~5 ns,
+            lane swap ~4.8 ns per wave instruction and SIMD)."""
+            B, KD, L, N = shape[0], shape[1], shape[2], shape[3]
+            waves = B * KD * L * N / 64.0 / 1024.0
+            if kind == "fwd":
+                nominal_clk, measured_ns = 4 * 2.1 + 8.1, 9.97
+            else:
+                nominal_clk, measured_ns = 12 * 2.1 + 8.1 + 8.1 + 2.1, 12 * 1.0 + 5.0 + 4.8
+            return waves * nominal_clk / 2.1e3, waves * measured_ns * 1e-3          # microseconds
+
         roof = None
         if rows:
             d = rows[0]
@@ -313,6 +328,9 @@ def main():
                         avg_launch_us=round(d["avg_us"], 1), launches=d["launches"],
                         share_of_scan_time=round(d["total_ms"] / scan_ms, 3),
                         scan_share_of_step=round((scan_ms / eager_scan_steps) / (elapsed / a.steps * 1e3), 3))
+            vf_nom, vf_meas = valu_floor(d["kernel"][5:], d["shape"])
+            roof.update(valu_floor_us=round(vf_nom, 1), valu_frac=round(vf_nom / d["avg_us"], 4),
+                        valu_floor_measured_us=round(vf_meas, 1), valu_frac_measured=round(vf_meas / d["avg_us"], 4))
         roof_fwd = None
         fwd_rows = [r for r in rows if r["kernel"] == "scan_fwd"]
         if fwd_rows:
@@ -321,6 +339,9 @@ def main():
                             frac=round(d["GBs"] / HBM_PEAK_GBS, 4), traffic=measured_traffic("fwd", d["shape"]),
                             algorithmic_bytes=int(d["algorithmic_MB"] * 1e6), kernel=d["kernel"], shape=d["shape"],
                             avg_launch_us=round(d["avg_us"], 1), launches=d["launches"])
+            vf_nom, vf_meas = valu_floor("fwd", d["shape"])
+            roof_fwd.update(valu_floor_us=round(vf_nom, 1), valu_frac=round(vf_nom / d["avg_us"], 4),
+                            valu_floor_measured_us=round(vf_meas, 1), valu_frac_measured=round(vf_meas / d["avg_us"], 4))
         if a.kernel_report:
             os.makedirs(os.path.dirname(os.path.abspath(a.kernel_report)) or ".", exist_ok=True)
             with open(a.kernel_report, "w") as f:

@@ -36,6 +36,14 @@
 // swaps + 60 DPP adds.  Results identical to the oracle's tolerance, but (16,3072,1200,N16) runs in 1083 us against 748:
 // the f32 MFMA holds its SIMD for ~80 clocks next to dependent VALU work, not the 32 of a bare MFMA stream.
 // 0 (default): the transpose-reduce network on the vector ALU.
+// 1: B / C of the next tile are pulled into L2 a tile ahead by one vector load per wave (round 4); 0: A/B builds without
+// development only: a deliberately mis-counted wait (tests/test_isa_waits_cpu.py must refuse such a build)
+#ifndef SIGMA_BWDR_WAIT_SKEW
+#define SIGMA_BWDR_WAIT_SKEW 0
+#endif
+#ifndef SIGMA_BWDR_TOUCH
+#define SIGMA_BWDR_TOUCH 1
+#endif
 #ifndef SIGMA_RL_MFMA
 #define SIGMA_RL_MFMA 0
 #endif
@@ -372,7 +380,7 @@ __device__ __forceinline__ void scan_bwdr_body(const BwdArgs& q, float* smem, co
         // after its requests (the touch, NS checkpoint loads, NS dB/dC stores, du, ddelta), which stay in
         // flight; the partial tile may skip some of them, so it (and the step after it: the caller waits) drains the counter.
         // (whole-tile walk: the touch, ONE checkpoint load, NS dB/dC stores, du, ddelta)
-        if (TAIL) rl_dma_wait(); else rl_dma_wait_keep<SIGMA_BWDR_FULL ? 4 + NS : 3 + 2 * NS>();
+        if (TAIL) rl_dma_wait(); else rl_dma_wait_keep<(SIGMA_BWDR_FULL ? 3 + NS : 2 + 2 * NS) + (SIGMA_BWDR_TOUCH ? 1 : 0) + SIGMA_BWDR_WAIT_SKEW>();
         RLPROF(8)                                                   // wait for this tile's u / delta / dout (LDS-DMA)
         const v4f uu = sRaw[tid], dd = sRaw[256 + tid];
         v4f g4 = sRaw[512 + tid];
@@ -403,7 +411,9 @@ __device__ __forceinline__ void scan_bwdr_body(const BwdArgs& q, float* smem, co
             d_nx = rl_load4u(d_blk + d_off - 4 * cc, T * mn + 4 * cc, more && T * mn + 4 * cc < L);
             g_nx = rl_load4u(g_blk + g_off - 4 * cc, T * mn + 4 * cc, more && T * mn + 4 * cc < L);
 #endif
+#if SIGMA_BWDR_TOUCH
             touch_nx = bc_touch[T * mn];
+#endif
         }
         RLPROF(10)                                                  // requests of the next tile
         {

@@ -50,6 +50,12 @@ class EncoderDecoder(nn.Module):
         if os.environ.get("SIGMA_TUNED_GEMMS") == "1":
             from ..tuning import enable_tuned_gemms
             enable_tuned_gemms()
+        else:
+            from ..tuning import table_path, tuned_gemms_requested
+            if os.path.exists(table_path()) and not tuned_gemms_requested() and not getattr(EncoderDecoder, "_tuning_note", False):
+                EncoderDecoder._tuning_note = True           # once per process
+                logger.info("sigma_amd: the tuned vendor-GEMM table %s is NOT in use (a few per cent of the step): set "
+                            "SIGMA_TUNED_GEMMS=1 or call sigma_amd.tuning.enable_tuned_gemms() before training", table_path())
         self.norm_layer = norm_layer
         if cfg.backbone not in _BACKBONES:
             raise NotImplementedError(

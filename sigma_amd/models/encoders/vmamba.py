@@ -666,7 +666,12 @@ class Backbone_VSSM(nn.Module):
         the vendor convolution library is out of the stem.  SIGMA_GEMM=fp32 / CPU tensors keep nn.Conv2d."""
         conv, norm = self.patch_embed[0], self.patch_embed[2]
         p = conv.kernel_size
-        if (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and isinstance(conv, nn.Conv2d) and _gemm.gemm_mode() == "split3"
+        # (a channels_last / cropped / flipped view keeps the layout-agnostic nn.Conv2d path, as do modules with forward hooks
+        # on the stem, which this shortcut would skip -- ADVICE r5)
+        hooked = bool(self.patch_embed._forward_hooks or self.patch_embed._forward_pre_hooks or conv._forward_hooks
+                      or conv._forward_pre_hooks or norm._forward_hooks or norm._forward_pre_hooks)
+        if (x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous() and not hooked
+                and isinstance(conv, nn.Conv2d) and _gemm.gemm_mode() == "split3"
                 and conv.stride == p and conv.padding == (0, 0) and conv.dilation == (1, 1) and conv.groups == 1
                 and x.shape[2] % p[0] == 0 and x.shape[3] % p[1] == 0 and (conv.in_channels * p[0] * p[1]) % 4 == 0
                 and conv.weight.dtype == torch.float32):

@@ -57,6 +57,11 @@ import os as _os
 _CKPT_ENV = _os.environ.get("SIGMA_CKPT_PITCH", "auto")
 
 
+def rowlane_possible() -> bool:
+    """False when SIGMA_CKPT_PITCH rules the row-lane kernels (checkpoint pitch 16) out for every launch of this process."""
+    return _CKPT_ENV in ("auto", "16")
+
+
 def rowlane_pays(seqlen: int, dstate: int, rows: int, groups: int) -> bool:
     """Launch shapes on which the row-lane kernels (csrc/scan_fwdr.hip / scan_bwdr.hip, checkpoint pitch 16) beat the
     quad-row / 64-lane kernels in forward + backward time, from the shape-by-shape comparison on MI355X

@@ -157,7 +157,9 @@ def make_graphed_step(net: nn.Module, opt, batch: Tuple[torch.Tensor, ...], warm
     from .selective_scan_cuda_core import rowlane_selftest
     if gemm_mode() == "split3":
         selftest(static[0].device)                           # not inside the capture (warmup=0)
-    rowlane_selftest(static[0].device)
+    from .ss2d_fused import rowlane_possible
+    if rowlane_possible():                                   # not when SIGMA_CKPT_PITCH forbids the row-lane kernels
+        rowlane_selftest(static[0].device)
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):                            # warm-up off the capture stream: lazy inits, LDS caps
@@ -244,7 +246,9 @@ def make_graphed_ddp_step(model: nn.Module, opt, batch: Tuple[torch.Tensor, ...]
     from .selective_scan_cuda_core import rowlane_selftest
     if gemm_mode() == "split3":
         selftest(static[0].device)
-    rowlane_selftest(static[0].device)
+    from .ss2d_fused import rowlane_possible
+    if rowlane_possible():                                   # not when SIGMA_CKPT_PITCH forbids the row-lane kernels
+        rowlane_selftest(static[0].device)
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):

@@ -10,7 +10,9 @@ shape of the training step once (PyTorch TunableOp) on an MI355X; the table is c
 PyTorch validates the table against the ROCm / hipBLASLt / rocBLAS versions recorded in it and ignores
 it on a mismatch, in which case the default heuristics apply.
 
-``SIGMA_TUNED_GEMMS=0`` disables the lookup (A/B runs)."""
+One variable, one meaning: ``SIGMA_TUNED_GEMMS=0`` forbids the lookup everywhere (A/B runs); entry points (bench.py,
+tools/) call ``enable_tuned_gemms()`` themselves; ``SIGMA_TUNED_GEMMS=1`` additionally makes the model constructor call it,
+for an unchanged reference ``train.py`` (the constructor alone never flips the process-wide switch)."""
 from __future__ import annotations
 
 import os
@@ -18,6 +20,15 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 TABLE = os.path.join(_HERE, "tuning", "tunableop_mi355x.csv")
 _state = {"enabled": None}
+
+
+def table_path() -> str:
+    return TABLE
+
+
+def tuned_gemms_requested() -> bool:
+    """True once enable_tuned_gemms() has switched the lookup on in this process."""
+    return bool(_state["enabled"])
 
 
 def enable_tuned_gemms(table: str = TABLE) -> bool:

@@ -19,10 +19,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 VMEM = re.compile(r"^\s+(global_load|global_store|global_atomic|buffer_|scratch_|flat_)")
 
 
-def _asm(tmp_path_factory):
+def _asm(tmp_path_factory, extra=()):
     from sigma_amd import build
     out = tmp_path_factory.mktemp("isa") / "scan_bwdr.s"
-    flags = [f for f in build.FLAGS if f != "-fPIC"]
+    flags = [f for f in build.FLAGS if f != "-fPIC"] + list(extra)
     subprocess.check_call([build.HIPCC, *flags, "--offload-device-only", "-S", os.path.join(build.CSRC, "scan_bwdr.hip"), "-o", str(out)],
                           stderr=subprocess.DEVNULL)
     return out.read_text().split("\n")
@@ -30,8 +30,9 @@ def _asm(tmp_path_factory):
 
 @pytest.fixture(scope="module")
 def asm(tmp_path_factory):
-    if not os.path.exists("/opt/rocm/bin/hipcc") and not os.environ.get("HIPCC"):
-        pytest.skip("no hipcc")
+    from sigma_amd import build
+    if not os.path.exists(build.HIPCC):                     # the compiler the build itself would use
+        pytest.skip(f"no hipcc at {build.HIPCC}")
     return _asm(tmp_path_factory)
 
 
@@ -69,15 +70,33 @@ def check_counted_wait(body):
         assert not inner, f"control flow inside the tile loop (line {inner[0]}): the static count below would not hold on every path"
         dma = [j for j in range(h, b) if "global_load_lds_dwordx4" in body[j]]
         assert len(dma) == 3, "three LDS-DMA requests per tile"
-        waits = [(j, int(m.group(1))) for j in range(h, dma[0]) for m in [re.search(r"s_waitcnt.*vmcnt\((\d+)\)", body[j].split(";")[0])] if m]
-        assert waits, "no vmcnt wait between the loop header and the requests of the next tile"
-        w, keep = waits[0]
-        younger = [j for j in list(range(dma[-1] + 1, b)) + list(range(h, w)) if VMEM.match(body[j])]
-        assert len(younger) >= keep, (f"only {len(younger)} vector-memory operations follow the LDS-DMA requests of a tile, but the wait in "
-                                      f"front of their read-back keeps {keep} in flight: the last request would not be waited for")
+        # the read-back of the landed bytes = the first LDS read after the loop header; every vmcnt wait in front of it
+        # counts (the compiler may add waits of its own for loop-carried loads): the bytes are there if ONE of them keeps
+        # no more operations in flight than vector-memory operations were issued between the requests and that wait
+        first_read = next((j for j in range(h, dma[0]) if re.match(r"\s+ds_read", body[j])), dma[0])
+        waits = [(j, int(m.group(1))) for j in range(h, first_read) for m in [re.search(r"s_waitcnt.*vmcnt\((\d+)\)", body[j].split(";")[0])] if m]
+        assert waits, "no vmcnt wait between the loop header and the read-back of the LDS-DMA bytes"
+        report = []
+        for w, keep in waits:
+            younger = [j for j in list(range(dma[-1] + 1, b)) + list(range(h, w)) if VMEM.match(body[j])]
+            report.append((keep, len(younger)))
+        assert any(n >= keep for keep, n in report), (
+            "no wait in front of the read-back covers the LDS-DMA requests of a tile: (kept in flight, vector-memory operations issued "
+            f"after the requests) = {report}: the last request would not be waited for")
     return len(loops)
 
 
 @pytest.mark.parametrize("ns,mode", [(4, 0), (2, 0), (1, 0), (4, 2)], ids=["N16", "N8", "N4", "N16-chained"])
 def test_counted_wait_of_the_row_lane_backward_is_covered_by_younger_operations(asm, ns, mode):
     assert check_counted_wait(_function(asm, ns, mode)) >= 1
+
+
+def test_a_miscounted_wait_is_refused(tmp_path_factory):
+    """the check has teeth: a build whose wait keeps three operations too many in flight (the build a run-time self test on an
+    idle chip passes, tools/diag/README.md) fails it"""
+    from sigma_amd import build
+    if not os.path.exists(build.HIPCC):
+        pytest.skip(f"no hipcc at {build.HIPCC}")
+    bad = _asm(tmp_path_factory, extra=["-DSIGMA_BWDR_WAIT_SKEW=3"])
+    with pytest.raises(AssertionError, match="no wait in front of the read-back covers"):
+        check_counted_wait(_function(bad, 4, 0))
