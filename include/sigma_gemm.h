@@ -57,6 +57,19 @@ typedef struct sigma_gemm_params {
                               gradients of the scan joined with the projection's (dxs = W^T dp + du[dir] + du[dir^1]) */
     const float *residual2;/* second addend with the same ldr / strideR, or NULL                                       */
     int64_t ldr, strideR;
+    /* ABI 10 (round 6) */
+    float *Ct;             /* nt only, with t_cols > 0: columns [0, t_cols) of the product are written TRANSPOSED,
+                              element (m, n) at Ct[n * ldct + m], and C receives only the columns n >= t_cols, element
+                              (m, n) at C[m * ldc + n - t_cols].  SS2D.in_proj (vmamba.py:1067-1071) thus hands its x half
+                              to the depthwise convolution channel-major, with no transposing pass in between.
+                              Needs t_cols % 32 == 0, M % 4 == 0, ldct % 4 == 0, 16-byte aligned Ct and C, N % 4 == 0,
+                              ldc % 4 == 0, batch <= 1, accumulate = 0, no residual                                       */
+    int64_t ldct;
+    int32_t t_cols;
+    int32_t k_slices;      /* nn only: 1 = the reduction may be cut into slices run by different workgroups and summed
+                              into C with fp32 atomics, as tn does (the CALLER zero-fills C, or passes accumulate = 1):
+                              products with few output tiles and a long reduction, e.g. the weight gradient
+                              dW = dX^T X with dX held channel-major                                                       */
 } sigma_gemm_params;
 
 /*   sigma_gemm_nt_split3

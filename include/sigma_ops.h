@@ -49,6 +49,10 @@ typedef struct sigma_dwconv_params {
     float *dweight;        /* (d, 1, 3, 3) ACCUMULATED into (caller zeroes)                        */
     float *dbias;          /* (d) ACCUMULATED into, or NULL                                        */
     float *dx;             /* (B, d, H, W) fully written                                           */
+    /* ABI 10: planes of x and dx need not be packed as (B, d): plane (b, c) starts at b * x_batch_stride + c * x_channel_stride
+     * floats (each plane H*W contiguous); 0 / 0 = the contiguous (B, d, H, W) tensor.  SS2D hands the x half of in_proj over
+     * in CHANNEL-major order (d, B, H, W) -- written transposed by the GEMM epilogue (sigma_gemm.h, t_cols), read here in place. */
+    int64_t x_batch_stride, x_channel_stride;
 } sigma_dwconv_params;
 
 int sigma_dwconv3x3_silu_fwd(const sigma_dwconv_params *params, void *stream);

@@ -77,6 +77,7 @@ class DwConvParams(ctypes.Structure):
         ("out2", ctypes.c_void_p),
         ("g2", ctypes.c_void_p), ("gpre", ctypes.c_void_p), ("dweight", ctypes.c_void_p), ("dbias", ctypes.c_void_p),
         ("dx", ctypes.c_void_p),
+        ("x_batch_stride", ctypes.c_int64), ("x_channel_stride", ctypes.c_int64),
     ]
 
 
@@ -124,6 +125,7 @@ class GemmParams(ctypes.Structure):
         ("a_mod", ctypes.c_int32), ("pieces", ctypes.c_int32),
         ("c_mod", ctypes.c_int32), ("reserved", ctypes.c_int32),
         ("residual", ctypes.c_void_p), ("residual2", ctypes.c_void_p), ("ldr", ctypes.c_int64), ("strideR", ctypes.c_int64),
+        ("Ct", ctypes.c_void_p), ("ldct", ctypes.c_int64), ("t_cols", ctypes.c_int32), ("k_slices", ctypes.c_int32),
     ]
 
 

@@ -34,7 +34,14 @@ struct DwArgs {
     float* dw; float* dbias;   // (d, 9), (d): accumulated
     float* dx;              // bwd2 out: (B, d, H, W)
     int B, d, H, W, orders;
+    long x_bs, x_cs;        // plane (b, c) of x / dx at b * x_bs + c * x_cs floats (packed: d * L, L)
 };
+
+// first element of plane `plane_id` = b * d + c of x / dx (the other tensors are packed)
+__device__ __forceinline__ long x_plane_offset(const DwArgs& a, int plane_id) {
+    const int b = plane_id / a.d, c = plane_id - b * a.d;
+    return (long)b * a.x_bs + (long)c * a.x_cs;
+}
 
 __device__ __forceinline__ float sigmoidf_fast(float v) {
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-v * 1.4426950408889634f));
@@ -69,7 +76,7 @@ __global__ void __launch_bounds__(256) dwconv_silu_fwd_kernel(const DwArgs a) {
     const int b = plane_id / a.d;
     const int w0 = (tile_id % tw) * kTile, h0 = (tile_id / tw) * kTile;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const float* __restrict__ plane = a.x + (long)plane_id * L;
+    const float* __restrict__ plane = a.x + x_plane_offset(a, plane_id);
     float* __restrict__ o_rm = a.out2 + ((long)(b * a.orders + 0) * a.d + c) * L;
     float* __restrict__ o_cm = a.out2 + ((long)(b * a.orders + 1) * a.d + c) * L;
     float wk[9];
@@ -115,7 +122,7 @@ __global__ void __launch_bounds__(256) dwconv_silu_bwd1_kernel(const DwArgs a) {
     const int b = plane_id / a.d;
     const int w0 = (tile_id % tw) * kTile, h0 = (tile_id / tw) * kTile;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const float* __restrict__ plane = a.x + (long)plane_id * L;
+    const float* __restrict__ plane = a.x + x_plane_offset(a, plane_id);
     const float* __restrict__ g_rm = a.g2 + ((long)(b * a.orders + 0) * a.d + c) * L;
     const float* __restrict__ g_cm = a.g2 + ((long)(b * a.orders + 1) * a.d + c) * L;
     float* __restrict__ gp = a.gpre + (long)plane_id * L;
@@ -182,7 +189,7 @@ __global__ void __launch_bounds__(256) dwconv_bwd2_kernel(const DwArgs a) {
     const int w0 = (tile_id % tw) * kTile, h0 = (tile_id / tw) * kTile;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     const float* __restrict__ gp = a.gpre + (long)plane_id * L;
-    float* __restrict__ dx = a.dx + (long)plane_id * L;
+    float* __restrict__ dx = a.dx + x_plane_offset(a, plane_id);
     float wk[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) wk[i] = a.w[c * 9 + i];
@@ -218,7 +225,7 @@ __global__ void __launch_bounds__(256) dwconv_silu_fwd_plane_kernel(const DwArgs
     const int plane_id = blockIdx.x;
     const int c = plane_id % a.d, b = plane_id / a.d;
     const int tid = threadIdx.x;
-    const float* __restrict__ plane = a.x + (long)plane_id * L;
+    const float* __restrict__ plane = a.x + x_plane_offset(a, plane_id);
     float* __restrict__ o_rm = a.out2 + ((long)(b * a.orders + 0) * a.d + c) * L;
     float* __restrict__ o_cm = a.out2 + ((long)(b * a.orders + 1) * a.d + c) * L;
     for (int i = tid; i < (H + 2) * pitch; i += 256) sIn[i] = 0.0f;
@@ -264,10 +271,10 @@ __global__ void __launch_bounds__(256) dwconv_silu_bwd_plane_kernel(const DwArgs
     const int plane_id = blockIdx.x;
     const int c = plane_id % a.d, b = plane_id / a.d;
     const int tid = threadIdx.x;
-    const float* __restrict__ plane = a.x + (long)plane_id * L;
+    const float* __restrict__ plane = a.x + x_plane_offset(a, plane_id);
     const float* __restrict__ g_rm = a.g2 + ((long)(b * a.orders + 0) * a.d + c) * L;
     const float* __restrict__ g_cm = a.g2 + ((long)(b * a.orders + 1) * a.d + c) * L;
-    float* __restrict__ dx = a.dx + (long)plane_id * L;
+    float* __restrict__ dx = a.dx + x_plane_offset(a, plane_id);
     for (int i = tid; i < 2 * (H + 2) * pitch; i += 256) smem[i] = 0.0f;
     __syncthreads();
     if ((W & 3) == 0 && (reinterpret_cast<uintptr_t>(plane) & 15u) == 0) {
@@ -361,6 +368,17 @@ dim3 grid_for(const sigma_dwconv_params* p) {
 
 }  // namespace sigma
 
+namespace sigma {
+// plane strides of x / dx: 0 / 0 = packed (B, d, H, W); otherwise both given, planes contiguous and non-overlapping
+bool plane_strides(const sigma_dwconv_params* p, DwArgs& a) {
+    const long L = (long)p->height * p->width;
+    if (p->x_batch_stride == 0 && p->x_channel_stride == 0) { a.x_bs = (long)p->channels * L; a.x_cs = L; return true; }
+    if (p->x_batch_stride < L || p->x_channel_stride < L) return false;
+    a.x_bs = p->x_batch_stride; a.x_cs = p->x_channel_stride;
+    return true;
+}
+}  // namespace sigma
+
 extern "C" {
 
 int sigma_dwconv3x3_silu_fwd(const sigma_dwconv_params* p, void* stream) {
@@ -371,6 +389,7 @@ int sigma_dwconv3x3_silu_fwd(const sigma_dwconv_params* p, void* stream) {
     sigma::DwArgs a{};
     a.x = p->x; a.w = p->weight; a.bias = p->bias; a.out2 = p->out2;
     a.B = p->batch; a.d = p->channels; a.H = p->height; a.W = p->width; a.orders = p->n_orders;
+    if (!sigma::plane_strides(p, a)) return SIGMA_OPS_ERR_ARG;
     if (const size_t lds = sigma::plane_lds_bytes(p))
         hipLaunchKernelGGL(sigma::dwconv_silu_fwd_plane_kernel, dim3((unsigned)(p->batch * p->channels)), dim3(256), lds,
                            static_cast<hipStream_t>(stream), a);
@@ -388,6 +407,7 @@ int sigma_dwconv3x3_silu_bwd(const sigma_dwconv_params* p, void* stream) {
     a.x = p->x; a.w = p->weight; a.bias = p->bias; a.g2 = p->g2; a.gpre = p->gpre;
     a.dw = p->dweight; a.dbias = p->dbias; a.dx = p->dx;
     a.B = p->batch; a.d = p->channels; a.H = p->height; a.W = p->width; a.orders = p->n_orders;
+    if (!sigma::plane_strides(p, a)) return SIGMA_OPS_ERR_ARG;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (const size_t lds = sigma::plane_lds_bytes(p)) {      // one launch, gpre stays in LDS (p->gpre is not written)
         hipLaunchKernelGGL(sigma::dwconv_silu_bwd_plane_kernel, dim3((unsigned)(p->batch * p->channels)), dim3(256), lds, s, a);

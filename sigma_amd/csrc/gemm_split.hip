@@ -61,6 +61,9 @@ struct GemmArgs {
     int c_mod;              // > 0: C of batch z is C + (z % c_mod) * sC  (mode 2: the problems sharing it are summed)
     const float* R; const float* R2;   // epilogue addends (or null), row stride ldr, batch stride sR
     long ldr, sR;
+    // columns [0, t_cols) of the result go TRANSPOSED to Ct[col * ldct + row] (row-contiguous epilogue only, t_cols % 32 == 0);
+    // columns >= t_cols to C[row * ldc + col - t_cols]
+    float* Ct; long ldct; int t_cols;
 };
 
 // P bf16 pieces of two floats (packed pairs): piece[0] = bf16(x), piece[1] = bf16(x - piece[0]), piece[2] = bf16 of the
@@ -260,7 +263,7 @@ gemm_split3_kernel(const GemmArgs g) {
         // XCD runs at the same time stream the same k-range of both operands -- each slice of A and B then comes from HBM once
         // per XCD instead of once per row / column tile (the tile-major order shares only the A slice among the column
         // tiles).  One division chain for both orders (selects on wave-uniform values, no branch).
-        const bool slice_major = SIGMA_GEMM_SLICE_MAJOR && A_KS && B_KS && g.slices > 1;
+        const bool slice_major = SIGMA_GEMM_SLICE_MAJOR && B_KS && g.slices > 1;
         const int d1 = slice_major ? g.ntm * g.ntn : g.ntn * g.slices;
         const int q1 = r0 / d1;
         const int rem = r0 - q1 * d1;
@@ -463,12 +466,41 @@ gemm_split3_kernel(const GemmArgs g) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) asm volatile("" : "+v"(bv[j]));
         }
-        float* stage = reinterpret_cast<float*>(smem) + wave * 1024;          // 32 x 32 floats of this wave
+        float* stage = reinterpret_cast<float*>(smem) + wave * 1056;          // 32 x 32 (33) floats of this wave
         const int wr = ((lane >> 5) << 2) * 32 + (lane & 31);                 // accumulator order: row 4 (l / 32) + ..., col l % 32
         const int rd_row = lane >> 3, rd_col = (lane & 7) << 2;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-            const int col = it.n0 + (wn * TN + j) * 32 + rd_col;
+            const int col0 = it.n0 + (wn * TN + j) * 32;
+            const int col = col0 + rd_col;
+            if (col0 < g.t_cols) {
+                // Transposed blocks (round 6: the x half of SS2D.in_proj leaves the GEMM channel-major, so that the depthwise
+                // conv reads it in place and the tiled transpose in front of it -- one read and one write of the
+                // activation per block -- is gone).  Staged with a row pitch of 33 floats: the accumulator-order writes
+                // stay conflict-free (32 consecutive floats per half wave) and the column reads below hit banks
+                // 4 (l % 8) + (l / 8) + 33 k, distinct inside each half wave.  A lane stores four consecutive ROWS of one
+                // column: 8 columns x 128 contiguous bytes per store instruction.
+                const int wr33 = ((lane >> 5) << 2) * 33 + (lane & 31);
+                const int rg = lane & 7, tc = lane >> 3;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) stage[wr33 + ((r & 3) + ((r >> 2) << 3)) * 33] = acc[i][j][r] + bv[j];
+                    const long rbase = it.m0 + (wm * TM + i) * 32 + 4 * rg;
+                    f32x4_t v[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float* src = stage + (4 * rg) * 33 + tc + 8 * q;
+                        v[q] = f32x4_t{src[0], src[33], src[66], src[99]};
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int c = col0 + tc + 8 * q;
+                        if (c < g.t_cols && rbase < g.M) *reinterpret_cast<f32x4_t*>(g.Ct + (long)c * g.ldct + rbase) = v[q];
+                    }
+                }
+                continue;
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -479,7 +511,7 @@ gemm_split3_kernel(const GemmArgs g) {
                 for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const f32x4_t*>(stage + (rd_row + 8 * q) * 32 + rd_col);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    f32x4_t* __restrict__ dst = reinterpret_cast<f32x4_t*>(it.Cb + (rbase + 8 * q) * g.ldc + col);
+                    f32x4_t* __restrict__ dst = reinterpret_cast<f32x4_t*>(it.Cb + (rbase + 8 * q) * g.ldc + (col - g.t_cols));
                     if (col < g.N && rbase + 8 * q < g.M) {
                         if (add) {
                             const f32x4_t old = *dst;
@@ -634,6 +666,7 @@ int fill_common(const sigma_gemm_params* p, GemmArgs& g) {
     g.slices = 1; g.a_mod = 0; g.c_mod = 0;
     g.mode = p->accumulate ? 1 : 0;
     g.R = p->residual; g.R2 = p->residual ? p->residual2 : nullptr; g.ldr = p->ldr; g.sR = p->strideR;
+    g.Ct = nullptr; g.ldct = 0; g.t_cols = 0;
     if (!p->residual && p->residual2) return SIGMA_OPS_ERR_ARG;
     if (p->residual && (p->ldr <= 0 || p->M * p->ldr >= 0x7fffffffL)) return SIGMA_OPS_ERR_ARG;
     if (p->c_mod < 0 || p->reserved != 0) return SIGMA_OPS_ERR_ARG;
@@ -658,6 +691,13 @@ extern "C" int sigma_gemm_nt_split3(const sigma_gemm_params* p, void* stream) {
         if (p->residual || p->bias) return SIGMA_OPS_ERR_ARG;
         g.c_mod = p->c_mod; g.mode = 2;
     } else if (p->c_mod > 0) g.c_mod = p->c_mod;
+    if (p->t_cols != 0) {                                // transposed column range: row-contiguous epilogue, plain stores only
+        if (p->t_cols < 0 || p->t_cols > p->N || p->t_cols % 32 != 0 || !p->Ct || !sigma::aligned16(p->Ct) || p->ldct % 4 != 0 ||
+            p->ldct < p->M || p->M % 4 != 0 || p->N % 4 != 0 || p->ldc % 4 != 0 || !sigma::aligned16(p->C) || batch != 1 ||
+            p->accumulate || p->residual || g.mode != 0 || !SIGMA_GEMM_ROW_EPILOGUE)
+            return SIGMA_OPS_ERR_ARG;
+        g.Ct = p->Ct; g.ldct = p->ldct; g.t_cols = p->t_cols;
+    }
     hipError_t e = sigma::launch_any<false, false>(g, batch, p->pieces, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? SIGMA_OPS_OK : SIGMA_OPS_ERR_LAUNCH;
 }
@@ -678,6 +718,20 @@ extern "C" int sigma_gemm_nn_split3(const sigma_gemm_params* p, void* stream) {
         if (p->residual || p->bias) return SIGMA_OPS_ERR_ARG;
         g.c_mod = p->c_mod; g.mode = 2;
     } else if (p->c_mod > 0) g.c_mod = p->c_mod;
+    if (p->k_slices == 1 && g.mode != 2 && !p->residual && !p->bias && batch == 1) {
+        // few output tiles, long reduction: slices summed with atomics, one round of resident workgroups (as tn)
+        const int bn = sigma::pick_bn(g.N);
+        const long tiles = ((g.M + 127) / 128) * ((g.N + bn - 1) / bn);
+        const long steps = (p->K + 31) / 32;
+        long want = 512 / (tiles > 0 ? tiles : 1);
+        if (want > steps / 8) want = steps / 8;
+        if (want > 1) {
+            const long per = (steps + want - 1) / want;
+            g.slice_k = (int)(per * 32);
+            g.slices = (int)((steps + per - 1) / per);
+            if (g.slices > 1) g.mode = 2;
+        }
+    }
     hipError_t e = sigma::launch_any<false, true>(g, batch, p->pieces, static_cast<hipStream_t>(stream));
     return e == hipSuccess ? SIGMA_OPS_OK : SIGMA_OPS_ERR_LAUNCH;
 }

@@ -38,7 +38,7 @@ MIN_DIM = 32               # smaller projections are launch / HBM bound either w
 
 
 def _params(M, N, K, A, Bt, C, bias, lda, ldb, ldc, accumulate=False, batch=1, sA=0, sB=0, sC=0, a_mod=0, pieces=2, c_mod=0,
-            residual=None, residual2=None, ldr=0, sR=0):
+            residual=None, residual2=None, ldr=0, sR=0, out_t=None, ldct=0, t_cols=0, k_slices=0):
     p = _capi.GemmParams()
     p.M, p.N, p.K = int(M), int(N), int(K)
     p.A, p.Bt, p.C = A.data_ptr(), Bt.data_ptr(), C.data_ptr()
@@ -52,6 +52,8 @@ def _params(M, N, K, A, Bt, C, bias, lda, ldb, ldc, accumulate=False, batch=1, s
     p.residual = residual.data_ptr() if residual is not None else None
     p.residual2 = residual2.data_ptr() if residual2 is not None else None
     p.ldr, p.strideR = int(ldr), int(sR)
+    p.Ct = out_t.data_ptr() if out_t is not None else None
+    p.ldct, p.t_cols, p.k_slices = int(ldct), int(t_cols), int(k_slices)
     return p
 
 
@@ -150,8 +152,10 @@ def nn_ok(a: torch.Tensor, b: torch.Tensor) -> bool:
     return a.shape[1] % 4 == 0 and b.shape[1] % 4 == 0 and _rows_ok(a) and _rows_ok(b)
 
 
-def gemm_nn(a: torch.Tensor, b: torch.Tensor, out=None, accumulate=False, pieces: int = 2) -> torch.Tensor:
-    """out (M, N) (+)= a (M, K) @ b (K, N), b read row-major in place"""
+def gemm_nn(a: torch.Tensor, b: torch.Tensor, out=None, accumulate=False, pieces: int = 2, k_slices: bool = False) -> torch.Tensor:
+    """out (M, N) (+)= a (M, K) @ b (K, N), b read row-major in place.  ``k_slices``: few output tiles and a long reduction
+    (a weight gradient whose left operand is held channel-major): the kernel may cut K into slices summed with fp32 atomics;
+    ``out`` is then zero-filled here unless ``accumulate``."""
     _check2d(a, b)
     M, K = a.shape
     N = b.shape[1]
@@ -159,11 +163,14 @@ def gemm_nn(a: torch.Tensor, b: torch.Tensor, out=None, accumulate=False, pieces
         raise RuntimeError("gemm_nn: operands must be (M, K) and (K, N) with K % 4 == 0, N % 4 == 0 and 16-byte aligned rows")
     _check_aux("gemm_nn", None, out, N, a.device)
     if out is None:
-        out = torch.empty((M, N), device=a.device, dtype=torch.float32)
+        out = (torch.zeros if k_slices else torch.empty)((M, N), device=a.device, dtype=torch.float32)
     elif out.stride(1) != 1 or tuple(out.shape) != (M, N):
         raise RuntimeError("gemm_nn: out must be (M, N) with contiguous rows")
+    elif k_slices and not accumulate:
+        out.zero_()
     if M and N:
-        _run("sigma_gemm_nn_split3", _params(M, N, K, a, b, out, None, a.stride(0), b.stride(0), out.stride(0), accumulate, pieces=pieces), a.device)
+        _run("sigma_gemm_nn_split3", _params(M, N, K, a, b, out, None, a.stride(0), b.stride(0), out.stride(0),
+                                             accumulate or k_slices, pieces=pieces, k_slices=1 if k_slices else 0), a.device)
     return out
 
 
@@ -309,6 +316,76 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias=None, residual=None) -> t
         r2 = residual.reshape(-1, weight.shape[0])
     y2 = LinearSplit3Fn.apply(x2, weight, bias, r2)
     return y2.view(*x.shape[:-1], weight.shape[0])
+
+
+def xz_ok(x2: torch.Tensor, weight: torch.Tensor) -> bool:
+    """the in_proj GEMM with a transposed x half: (M, C) @ (2d, C)^T with d % 32 == 0, M % 4 == 0, two bf16 pieces forward"""
+    return (_FWD == 2 and x2.is_cuda and x2.dtype == torch.float32 and weight.dtype == torch.float32 and x2.dim() == 2
+            and weight.shape[0] % 64 == 0 and x2.shape[0] % 4 == 0 and x2.shape[0] > 0 and nt_ok(x2, weight))
+
+
+class LinearXZFn(torch.autograd.Function):
+    """SS2D.in_proj with its two consumers' layouts (vmamba.py:1067-1071: ``xz = in_proj(x); x, z = xz.chunk(2, -1);
+    x = x.permute(0, 3, 1, 2).contiguous()``):  (x2 (M, C), weight (2d, C), bias) -> xT (d, M) CHANNEL-major, z (M, d).
+
+    One GEMM writes both: the columns of the x half leave the kernel transposed (sigma_gemm.h, t_cols), so the depthwise
+    convolution reads (d, B, H, W) planes in place and the tiled transpose that round 3 put between the two (one read and one
+    write of the activation per block, and again in the backward) is gone.  Backward, from dxT (d, M) -- written channel-major
+    by the convolution's backward -- and dz (M, d):
+        dx2 = dz W_z + dxT^T W_x        nn, then tn with accumulate (reduction over the d channels: both operands slow-indexed)
+        dW  = [dxT x2 ; dz^T x2]        nn with the token reduction cut into slices (atomics), tn
+        db  = [sum_m dxT ; sum_m dz]"""
+
+    @staticmethod
+    def forward(ctx, x2, weight, bias):
+        M = x2.shape[0]
+        d = weight.shape[0] // 2
+        xT = torch.empty((d, M), device=x2.device, dtype=torch.float32)
+        z = torch.empty((M, d), device=x2.device, dtype=torch.float32)
+        _check_aux("linear_xz", bias, None, 2 * d, x2.device)
+        _run("sigma_gemm_nt_split3", _params(M, 2 * d, x2.shape[1], x2, weight, z, bias, x2.stride(0), weight.stride(0), d, pieces=2,
+                                             out_t=xT, ldct=M, t_cols=d), x2.device)
+        ctx.save_for_backward(x2, weight)
+        ctx.has_bias = bias is not None
+        return xT, z
+
+    @staticmethod
+    def backward(ctx, dxT, dz):
+        x2, weight = ctx.saved_tensors
+        M, C = x2.shape
+        d = weight.shape[0] // 2
+        dxT = torch.zeros((d, M), device=x2.device, dtype=torch.float32) if dxT is None else (dxT if _rows_ok(dxT) else dxT.contiguous())
+        dz = torch.zeros((M, d), device=x2.device, dtype=torch.float32) if dz is None else (dz if _rows_ok(dz) else dz.contiguous())
+        w_x, w_z = weight[:d], weight[d:]
+        dx2 = dw = db = None
+        if ctx.needs_input_grad[0]:
+            if _DGRAD and nn_ok(dz, w_z) and tn_ok(dxT, w_x):
+                dx2 = gemm_nn(dz, w_z, pieces=_DGRAD)
+                gemm_tn(dxT, w_x, out=dx2, accumulate=True, pieces=_DGRAD)
+            else:
+                dx2 = torch.mm(dz, w_z) + torch.mm(dxT.t(), w_x)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(weight)
+            if _WGRAD and nn_ok(dxT, x2) and tn_ok(dz, x2):
+                gemm_nn(dxT, x2, out=dw[:d], pieces=_WGRAD, k_slices=True)
+                gemm_tn(dz, x2, out=dw[d:], pieces=_WGRAD)
+            else:
+                dw[:d] = torch.mm(dxT, x2)
+                dw[d:] = torch.mm(dz.t(), x2)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = torch.cat([dxT.sum(1), dz.sum(0)])
+        return dx2, dw, db
+
+
+def linear_xz(x: torch.Tensor, weight: torch.Tensor, bias=None):
+    """in_proj of an SS2D block on a channels-last (B, H, W, C) input: returns (xi, z) with xi the (B, d, H, W) VIEW of a
+    channel-major (d, B, H, W) buffer (its H x W planes are contiguous: csrc/dwconv.hip reads them in place) and z the
+    (B, H, W, d) gate tensor.  Callers check ``xz_ok`` first."""
+    B, H, W, C = x.shape
+    x2 = x.reshape(-1, C)
+    d = weight.shape[0] // 2
+    xT, z = LinearXZFn.apply(x2, weight, bias)
+    return xT.view(d, B, H, W).permute(1, 0, 2, 3), z.view(B, H, W, d)
 
 
 def _forward(self, x):

@@ -44,6 +44,7 @@ from ...ss2d_fused import (dwconv_silu, dwconv_silu_two_orders, selective_scan_e
 _FUSED_SS2D = os.environ.get("SIGMA_SS2D_FUSED", "1") != "0"
 _FUSED_GATE = os.environ.get("SIGMA_FUSED_GATE", "1") != "0"      # out_norm * silu(z) as one HIP pass
 _FUSED_SPLIT = os.environ.get("SIGMA_FUSED_SPLIT", "1") != "0"    # chunk + permute as one tiled transpose
+_FUSED_XZ = os.environ.get("SIGMA_FUSED_XZ", "1") != "0"          # ... or none: in_proj writes its x half channel-major (round 6)
 
 
 # --------------------------------------------------------------------------- small helpers
@@ -242,12 +243,19 @@ class SS2D(nn.Module):
         ``residual``: optional tensor of the output's shape that is added to the result -- the block's residual stream,
         added inside the out_proj GEMM (its accumulators start from it) instead of in a pass of its own."""
         fold = branch_scale is not None and self.out_proj.bias is None and isinstance(self.dropout, nn.Identity)
-        xz = self.in_proj(x)
-        if _FUSED_SS2D and _FUSED_SPLIT and xz.is_cuda and xz.dtype == torch.float32:
-            xi, z = split_xz(xz)                                             # (B, d, H, W), view (B, H, W, d)
+        if (_FUSED_SS2D and _FUSED_SPLIT and _FUSED_XZ and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+                and _gemm.gemm_mode() == "split3" and not self.in_proj._forward_hooks and not self.in_proj._forward_pre_hooks
+                and _gemm.xz_ok(x.reshape(-1, x.shape[-1]), self.in_proj.weight)):
+            # round 6: ONE GEMM writes the x half channel-major (d, B, H, W) for the convolution and the z half
+            # channels-last for the gate -- no transposing pass between in_proj and the convolution, in either direction
+            xi, z = _gemm.linear_xz(x, self.in_proj.weight, self.in_proj.bias)   # (B, d, H, W) view, (B, H, W, d)
         else:
-            xi, z = xz.chunk(2, dim=-1)
-            xi = xi.permute(0, 3, 1, 2).contiguous()                         # (B, d, H, W)
+            xz = self.in_proj(x)
+            if _FUSED_SS2D and _FUSED_SPLIT and xz.is_cuda and xz.dtype == torch.float32:
+                xi, z = split_xz(xz)                                         # (B, d, H, W), view (B, H, W, d)
+            else:
+                xi, z = xz.chunk(2, dim=-1)
+                xi = xi.permute(0, 3, 1, 2).contiguous()                     # (B, d, H, W)
         if _FUSED_SS2D and xi.is_cuda:
             # depthwise conv + SiLU + both scan orders in one HIP pass, then the fused scan core
             Bq, dq, Hq, Wq = xi.shape

@@ -126,6 +126,21 @@ def _two_orders(x4: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def _planes_ok(x: torch.Tensor) -> bool:
+    """(B, d, H, W) whose H x W planes are contiguous and do not overlap: the packed tensor, or the permuted view of a
+    channel-major (d, B, H, W) buffer (include/sigma_ops.h, x_batch_stride / x_channel_stride)"""
+    if x.dim() != 4:
+        return False
+    B, d, H, W = x.shape
+    L = H * W
+    sb, sc, sh, sw = x.stride()
+    if (sh, sw) != (W, 1) and L > 1:
+        return False
+    if x.data_ptr() % 16:
+        return False
+    return (sb, sc) == (d * L, L) or (sc == B * L and sb == L) or (B == 1 and sc >= L) or (d == 1 and sb >= L)
+
+
 class DwConvSiLUTwoOrdersFn(torch.autograd.Function):
     """xs2 = [silu(dwconv3x3(x)) row-major, the same column-major]  (B, d, H, W) -> (B, 2, d, H*W).
 
@@ -139,7 +154,9 @@ class DwConvSiLUTwoOrdersFn(torch.autograd.Function):
         lib = _capi.load()
         if not x.is_cuda:
             raise RuntimeError("dwconv3x3_silu: GPU tensors only (no fallback)")
-        x = x.float().contiguous()
+        x = x.float()
+        if not _planes_ok(x):
+            x = x.contiguous()
         w = weight.float().contiguous()
         b = None if bias is None else bias.float().contiguous()
         B, d, H, W = x.shape
@@ -150,6 +167,7 @@ class DwConvSiLUTwoOrdersFn(torch.autograd.Function):
         p = _capi.DwConvParams()
         p.batch, p.channels, p.height, p.width, p.n_orders = B, d, H, W, n_orders
         p.x, p.weight, p.bias, p.out2 = x.data_ptr(), w.data_ptr(), (b.data_ptr() if b is not None else None), out2.data_ptr()
+        p.x_batch_stride, p.x_channel_stride = x.stride(0), x.stride(1)
         with torch.cuda.device(x.device):
             _capi.check(lib.sigma_dwconv3x3_silu_fwd(ctypes.byref(p), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
                         "dwconv3x3_silu_fwd")
@@ -165,14 +183,17 @@ class DwConvSiLUTwoOrdersFn(torch.autograd.Function):
         x, w, b = ctx.saved_tensors
         B, d, H, W = x.shape
         g2 = g2.float().contiguous()
-        gpre = torch.empty_like(x)
-        dx = torch.empty_like(x)
+        gpre = torch.empty(B, d, H, W, device=x.device, dtype=torch.float32)
+        # dx in the layout of x: the channel-major (d, B, H, W) buffer of the in_proj hand-over stays channel-major, so that
+        # LinearXZFn.backward reads it in place (gemm.py)
+        dx = torch.empty_strided(x.shape, x.stride(), device=x.device, dtype=torch.float32)
         dw = torch.zeros_like(w)
         db = torch.zeros(d, device=x.device, dtype=torch.float32) if ctx.has_bias else None
         p = _capi.DwConvParams()
         p.batch, p.channels, p.height, p.width, p.n_orders = B, d, H, W, ctx.n_orders
         p.x, p.weight, p.bias = x.data_ptr(), w.data_ptr(), (b.data_ptr() if ctx.has_bias else None)
         p.g2, p.gpre, p.dweight, p.dx = g2.data_ptr(), gpre.data_ptr(), dw.data_ptr(), dx.data_ptr()
+        p.x_batch_stride, p.x_channel_stride = x.stride(0), x.stride(1)
         p.dbias = db.data_ptr() if db is not None else None
         with torch.cuda.device(x.device):
             _capi.check(lib.sigma_dwconv3x3_silu_bwd(ctypes.byref(p), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)),
