@@ -512,10 +512,17 @@ FULL_LAUNCHES = [
     (16, 768, 19200, 16, 4, 0b1010, 1, 160),
     (2, 3072, 1200, 16, 4, 0b1010, 1, 16),
     (1, 768, 19200, 16, 4, 0b1010, 1, 16),
+    # round 6: the three largest 4-state launches of the batch-8 step -- decoder stage 0 (MambaDecoder.py:103,
+    # d_state 4), ConMB stage 0 (vmamba.py:369-430: K = 2, one direction reversed, the 2 L sequence) and decoder stage 1 --
+    # through the automatic policy: 64-lane kernels at pitch 640 for the long rows, quad-row at pitch 160 for (8,1536,4800)
+    (8, 768, 19200, 4, 4, 0b1010, 1, 640),
+    (8, 384, 38400, 4, 2, 0b10, 1, 640),
+    (8, 1536, 4800, 4, 4, 0b1010, 1, 160),
 ]
 
 
-@pytest.mark.parametrize("shape", FULL_LAUNCHES, ids=["16x3072x1200xN16", "16x768x19200xN16", "2x3072x1200xN16", "1x768x19200xN16"])
+@pytest.mark.parametrize("shape", FULL_LAUNCHES, ids=["16x3072x1200xN16", "16x768x19200xN16", "2x3072x1200xN16", "1x768x19200xN16",
+                                                      "8x768x19200xN4", "8x384x38400xN4", "8x1536x4800xN4"])
 def test_full_size_step_launches_against_oracle(shape):
     """The benchmarked launches AT THEIR REAL SIZE, with the pitch / kernels the fused model path (SS2DCoreFn) picks
     automatically -- ckpt_pitch_for called exactly as ss2d_fused calls it, with rowlane_ok of the operands and the group
