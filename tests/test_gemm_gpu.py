@@ -246,3 +246,81 @@ def test_stacked_gemms_refuse_what_they_cannot_take():
         gemm.bgemm_nt_sum(_rand(4, 8, 16), _rand(4, 24, 16), torch.zeros(3, 8, 24, device=DEV))
     with pytest.raises(RuntimeError):
         gemm.gemm_nt(_rand(8, 16), _rand(24, 16), residual=_rand(8, 20))
+
+
+# ---- round 6: in_proj with a channel-major x half (sigma_gemm.h t_cols), sliced reductions of the nn form ------------------
+
+XZ_SHAPES = [(2, 30, 40, 384, 768), (2, 6, 10, 96, 192), (1, 15, 20, 768, 1536), (2, 23, 40, 128, 256), (1, 3, 4, 32, 32)]
+
+
+@pytest.mark.parametrize("dims", XZ_SHAPES, ids=["x".join(map(str, d)) for d in XZ_SHAPES])
+@pytest.mark.parametrize("with_bias", [False, True], ids=["nobias", "bias"])
+def test_in_proj_with_channel_major_x_half_against_fp64(dims, with_bias):
+    """gemm.linear_xz (vmamba.py:1067-1071: in_proj, chunk, permute + contiguous of the x half): ONE GEMM whose x columns
+    leave the kernel transposed.  Forward and the gradients of x, weight and bias against the fp64 formulation; the x half is
+    a (B, d, H, W) view of a channel-major (d, B, H, W) buffer whose planes are contiguous."""
+    from sigma_amd import gemm
+    B, H, W, C, d = dims
+    x = _rand(B, H, W, C, seed=31).requires_grad_()
+    w = _rand(2 * d, C, seed=32, scale=0.05).requires_grad_()
+    b = _rand(2 * d, seed=33, scale=0.1).requires_grad_() if with_bias else None
+    assert gemm.xz_ok(x.reshape(-1, C), w)
+    xi, z = gemm.linear_xz(x, w, b)
+    assert tuple(xi.shape) == (B, d, H, W) and xi.stride()[2:] == (W, 1) and xi.stride(1) == B * H * W and z.is_contiguous()
+    x64, w64 = x.detach().double().requires_grad_(), w.detach().double().requires_grad_()
+    b64 = b.detach().double().requires_grad_() if with_bias else None
+    ref = torch.nn.functional.linear(x64, w64, b64)
+    bound = _bound(x64.detach().reshape(-1, C), w64.detach().t())
+    _assert_close(xi.permute(0, 2, 3, 1).reshape(-1, d), ref[..., :d].reshape(-1, d).detach(), bound[:, :d], "x half")
+    _assert_close(z.reshape(-1, d), ref[..., d:].reshape(-1, d).detach(), bound[:, d:], "z half")
+    gx, gz = _rand(*xi.shape, seed=34), _rand(*z.shape, seed=35)
+    ((xi * gx).sum() + (z * gz).sum()).backward()
+    ((ref[..., :d].permute(0, 3, 1, 2) * gx.double()).sum() + (ref[..., d:] * gz.double()).sum()).backward()
+    g2 = torch.cat([gx.permute(0, 2, 3, 1).reshape(-1, d), gz.reshape(-1, d)], 1).double()
+    _assert_close(x.grad.reshape(-1, C), x64.grad.reshape(-1, C), _bound(g2, w64.detach()), "dx")
+    _assert_close(w.grad, w64.grad, _bound(g2.t(), x64.detach().reshape(-1, C)), "dw")
+    if with_bias:
+        torch.testing.assert_close(b.grad.double(), b64.grad, rtol=1e-4, atol=1e-4 * float(b64.grad.abs().max()))
+
+
+def test_transposed_column_range_refuses_what_it_cannot_take():
+    """t_cols needs 32-column granularity, M % 4 == 0, plain stores (no accumulate / residual): SIGMA_OPS_ERR_ARG otherwise"""
+    from sigma_amd import gemm
+    a, w = _rand(64, 32, seed=1), _rand(128, 32, seed=2)
+    z, xt = torch.empty(64, 64, device=DEV), torch.empty(64, 64, device=DEV)
+    ok = gemm._params(64, 128, 32, a, w, z, None, 32, 32, 64, out_t=xt, ldct=64, t_cols=64)
+    gemm._run("sigma_gemm_nt_split3", ok, a.device)                                  # the legal call
+    want = a.double() @ w.double().t()
+    _assert_close(xt.t(), want[:, :64], _bound(a.double(), w.double().t())[:, :64], "transposed half")
+    _assert_close(z, want[:, 64:], _bound(a.double(), w.double().t())[:, 64:], "plain half")
+    for kw in (dict(t_cols=48), dict(t_cols=160), dict(ldct=60), dict(accumulate=True)):
+        args = dict(out_t=xt, ldct=64, t_cols=64)
+        acc = kw.pop("accumulate", False)
+        args.update(kw)
+        p = gemm._params(64, 128, 32, a, w, z, None, 32, 32, 64, acc, **args)
+        with pytest.raises(RuntimeError, match="sigma_gemm_nt_split3 failed"):
+            gemm._run("sigma_gemm_nt_split3", p, a.device)
+    a2 = _rand(66, 32, seed=3)                                                        # M % 4 != 0
+    p = gemm._params(66, 128, 32, a2, w, torch.empty(66, 64, device=DEV), None, 32, 32, 64, out_t=torch.empty(64, 68, device=DEV), ldct=68, t_cols=64)
+    with pytest.raises(RuntimeError, match="sigma_gemm_nt_split3 failed"):
+        gemm._run("sigma_gemm_nt_split3", p, a.device)
+
+
+@pytest.mark.parametrize("shape", [(768, 19200, 384), (192, 4800, 96), (1536, 300, 768), (64, 4096, 32), (130, 1000, 36)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_gemm_nn_with_a_sliced_reduction_against_fp64(shape):
+    """k_slices: few output tiles, a long reduction (dW_x = dx^T x with dx held channel-major): slices summed with atomics
+    into a zero-filled output; also into a row-slice view of a larger gradient tensor, and accumulating"""
+    from sigma_amd import gemm
+    M, K, N = shape
+    a, b = _rand(M, K, seed=41), _rand(K, N, seed=42, scale=0.05)
+    want = a.double() @ b.double()
+    bound = _bound(a.double(), b.double())
+    _assert_close(gemm.gemm_nn(a, b, k_slices=True), want, bound, "nn sliced")
+    big = torch.full((2 * M, N), 7.0, device=DEV)
+    gemm.gemm_nn(a, b, out=big[M:], k_slices=True)
+    _assert_close(big[M:], want, bound, "nn sliced into a view")
+    assert float((big[:M] - 7.0).abs().max()) == 0.0
+    acc = _rand(M, N, seed=43)
+    got = gemm.gemm_nn(a, b, out=acc.clone(), accumulate=True, k_slices=True)
+    _assert_close(got, want + acc.double(), bound + acc.double().abs(), "nn sliced accumulate")
