@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define SIGMA_SCAN_ABI_VERSION 9
+#define SIGMA_SCAN_ABI_VERSION 10
 
 /* dtype of u, delta, B, C, out, dout, du, ddelta  (input_t of the reference,
  * selective_scan.cpp:174: float / half / bfloat16).  A, D, delta_bias, x, dA,
@@ -217,6 +217,10 @@ int sigma_scan_abi_version(void);
  *   "rl_chain"                 row-lane backward: chained walk (row blocks laid end to end over exactly as many workgroups as
  *                              the chip holds, a cut row block hands its reverse carry to the neighbour): 2 = whenever
  *                              there are more row blocks than resident workgroups; 0 / 1 = never (measured: no gain)
+ *   "rl_chain_timeouts"        READ-ONLY (get_option; set_option refuses it): hand-over waits of the chained walk that ran
+ *                              out since the last read -- each one poisoned its row block's du / ddelta / dA with NaN (the
+ *                              producer workgroup was not resident: another stream's kernel held its slot).  Reading
+ *                              synchronises the device and resets the count; -1 on a device error.
  * Returns SIGMA_ERR_BAD_OPTION for unknown names / unsupported values. */
 int sigma_scan_set_option(const char *name, int value);
 int sigma_scan_get_option(const char *name);

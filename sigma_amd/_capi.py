@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # SIGMA_HIP_LIB lets a benchmark A/B an experimental build of the same ABI; default is the in-tree library
 LIB_PATH = os.environ.get("SIGMA_HIP_LIB") or os.path.join(_HERE, "lib", "libsigma_hip.so")
 
-SIGMA_SCAN_ABI_VERSION = 9
+SIGMA_SCAN_ABI_VERSION = 10
 SIGMA_SCAN_CHUNK = 2048
 SIGMA_SCAN_CKPT_PITCH = 1280
 SIGMA_SCAN_CKPT_PITCH_FINE = 640

@@ -621,6 +621,11 @@ int sigma_scan_set_option(const char* name, int value) {
 int sigma_scan_get_option(const char* name) {
     if (!name) return -1;
     for (auto& o : g_opts) if (!std::strcmp(name, o.name)) return o.var->load();
+    if (!std::strcmp(name, "rl_chain_timeouts")) {      // read-only: see sigma_scan.h
+        unsigned int n = 0;
+        if (sigma::bwdr_chain_timeouts_read(&n) != hipSuccess) return -1;
+        return (int)(n > 0x7fffffffu ? 0x7fffffffu : n);
+    }
     return -1;
 }
 

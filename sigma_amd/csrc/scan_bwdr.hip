@@ -51,8 +51,17 @@
 #if SIGMA_RL_PROF
 __device__ unsigned long long g_bwdr_prof[16];
 #endif
+__device__ unsigned int g_bwdr_chain_timeouts;     // chained walk: hand-over waits that ran out (their row blocks were poisoned)
 
 namespace sigma {
+
+// waits of the chained walk that ran out since the last call (synchronises the device; resets the counter)
+hipError_t bwdr_chain_timeouts_read(unsigned int* out) {
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_bwdr_chain_timeouts), sizeof(unsigned int));
+    if (e != hipSuccess || *out == 0) return e;
+    const unsigned int z = 0;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_bwdr_chain_timeouts), &z, sizeof(z));
+}
 
 #if SIGMA_RL_PROF
 hipError_t bwdr_prof_read(unsigned long long* out16) {
@@ -281,6 +290,7 @@ __device__ __forceinline__ void scan_bwdr_body(const BwdArgs& q, float* smem, co
                 __builtin_amdgcn_s_sleep(16);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             *timed_out = spin >= (1 << 22);
+            if (spin >= (1 << 22)) atomicAdd(&g_bwdr_chain_timeouts, 1u);   // "rl_chain_timeouts": the host can tell why there are NaNs
         }
         __syncthreads();
         // A wait that ran out (the producer is not resident: another stream's kernel holds its slot) must not pass for a

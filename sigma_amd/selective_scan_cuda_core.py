@@ -338,6 +338,17 @@ def bwd_ext(u, delta, A, B, C, D_, delta_bias_, dout, x_, delta_softplus, nrows:
             key = (batch, dim, seqlen, dstate, n_groups, u.element_size())
             _launch("bwd", key, lambda: _capi.check(
                 lib.sigma_selective_scan_bwd(ctypes.byref(bp), ctypes.c_void_p(stream)), "selective_scan_bwd"))
+            if (ckpt_pitch == _capi.SIGMA_SCAN_CKPT_PITCH_16 and lib.sigma_scan_get_option(b"rl_chain") == 2
+                    and not torch.cuda.is_current_stream_capturing()):
+                # The chained walk (on request only) poisons a row block with NaN when a hand-over wait runs out; say WHY
+                # here instead of leaving a NaN loss to be explained (costs a device synchronisation, in this mode only).
+                n = lib.sigma_scan_get_option(b"rl_chain_timeouts")
+                if n != 0:
+                    raise RuntimeError(
+                        f"selective_scan_bwd: {n if n > 0 else 'an unknown number of'} hand-over wait(s) of the chained "
+                        "row-lane walk ran out (the producer workgroup was not resident: another stream's kernel held "
+                        "its slot); the gradients of this call hold NaN. Unset the 'rl_chain' option or run the scan "
+                        "alone on the device")
     if dB_out is None:
         dB, dC = dB.to(B.dtype), dC.to(C.dtype)                                  # :360
     return [du, ddelta, dA, dB, dC, dD, ddelta_bias]

@@ -90,6 +90,9 @@ def test_options_and_launch_plan():
         _capi.set_option("fwd_items", 8)
     with pytest.raises(RuntimeError):
         _capi.set_option("no_such_option", 1)
+    with pytest.raises(RuntimeError):
+        _capi.set_option("rl_chain_timeouts", 0)          # read-only counter of the chained walk
+    assert _capi.get_option("no_such_option") == -1
     plan = (ctypes.c_int32 * 6)()
     # headline shape (1, 768, 19200), N=16, G=4: few rows -> the sequence is split inside the workgroup
     p = _params(batch=1, dim=768, seqlen=19200, dstate=16, n_groups=4, n_chunks=10)

@@ -696,6 +696,12 @@ def test_row_lane_kernels_against_oracle(case):
     segments (forced and automatic) and the chained walk."""
     shape, opts = case
     _rowlane_run(shape, opts)
+    if opts.get("rl_chain") == 2:
+        from sigma_amd import _capi
+        # no hand-over wait ran out (bwd_ext raises when one does; the count is read-only and resets on read)
+        assert _capi.get_option("rl_chain_timeouts") == 0
+        with pytest.raises(RuntimeError):
+            _capi.set_option("rl_chain_timeouts", 0)
 
 
 @pytest.mark.parametrize("flags", [dict(softplus=False), dict(with_D=False, with_bias=False), dict(softplus=False, with_D=False)],
