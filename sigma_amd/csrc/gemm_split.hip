@@ -141,10 +141,19 @@ struct TileLoader {
         const uintptr_t bq = reinterpret_cast<uintptr_t>(base);
         base = reinterpret_cast<const float*>(((uintptr_t)(unsigned)__builtin_amdgcn_readfirstlane((int)(bq >> 32)) << 32) |
                                               (unsigned)__builtin_amdgcn_readfirstlane((int)(bq & 0xffffffffu)));
+        // The full step and the partial last step of a reduction are two code paths behind a wave-uniform BRANCH (both hold
+        // volatile asm, so hipcc cannot turn the branch into selects): as selects the tail adjustment cost every full step
+        // 5 + NV VALU here and 2 selects per element in store() -- 64 of the ~210 VALU of a 128 x 128 k-step (round 6, ISA).
+        if (rem >= kBK) {
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            unsigned o = KS ? off[i >> 2] + (unsigned)(i & 3) * ldb4 : off[i];
-            if (rem < kBK) {                                              // wave-uniform: the last, partial k-step
+            for (int i = 0; i < NV; ++i) {
+                const unsigned o = KS ? off[i >> 2] + (unsigned)(i & 3) * ldb4 : off[i];
+                asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v[i]) : "v"(o), "s"(base) : "memory");
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                unsigned o = KS ? off[i >> 2] + (unsigned)(i & 3) * ldb4 : off[i];
                 if constexpr (!KS) {
                     const int kc = (t & 7) << 2;
                     if (kc >= rem) o -= (unsigned)(kc - (rem - 4)) * 4u;            // K % 4 == 0: re-read the last chunk
@@ -152,23 +161,30 @@ struct TileLoader {
                     const int kk = ((t & 7) << 2) + (i & 3);
                     if (kk >= rem) o -= (unsigned)((long)(kk - (rem - 1)) * ld * 4);
                 }
+                asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v[i]) : "v"(o), "s"(base) : "memory");
             }
-            asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(v[i]) : "v"(o), "s"(base) : "memory");
         }
     }
 
     // split into P bf16 images [row][k], image q at img + q * img_stride; elements past the reduction range are zero
     template <int P>
-    __device__ __forceinline__ void store(const f32x4_t (&v)[NV], int rem, uint16_t* __restrict__ img, int img_stride) const {
+    __device__ __forceinline__ void store(f32x4_t (&xs)[NV], int rem, uint16_t* __restrict__ img, int img_stride) const {
         const int t = threadIdx.x;
+        // only the last, partial k-step of a reduction masks (in place: the ring slot is refilled next): a wave-uniform
+        // branch the compiler cannot flatten (the empty volatile asm inside it), so the full step carries no selects
+        if (rem < kBK) {
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const bool ok = KS ? (((t & 7) << 2) + (i & 3) < rem) : (((t & 7) << 2) < rem);
+                xs[i] = ok ? xs[i] : f32x4_t{0.f, 0.f, 0.f, 0.f};
+                asm volatile("" : "+v"(xs[i]));
+            }
+        }
         if constexpr (!KS) {
-            // only the last, partial k-step of a reduction masks (wave-uniform branch: the full step carries no selects)
-            const bool ok = rem >= kBK || ((t & 7) << 2) < rem;
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
                 const int o = ((t >> 3) + 32 * i) * kPitch + ((t & 7) << 2);
-                f32x4_t x = v[i];
-                if (rem < kBK) x = ok ? x : f32x4_t{0.f, 0.f, 0.f, 0.f};
+                const f32x4_t x = xs[i];
                 unsigned p01[P], p23[P];
                 split_pair<P>(x[0], x[1], p01);
                 split_pair<P>(x[2], x[3], p23);
@@ -180,19 +196,12 @@ struct TileLoader {
             for (int i = 0; i < NV / 4; ++i) {
                 int ch = (t >> 3) + 32 * i;
                 ch = ch < ROWS / 4 ? ch : ROWS / 4 - 1;                   // repeated chunk: same values, same address
-                f32x4_t x[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) x[j] = v[4 * i + j];
-                if (rem < kBK) {                                          // wave-uniform: the last, partial k-step
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) x[j] = (((t & 7) << 2) + j < rem) ? x[j] : f32x4_t{0.f, 0.f, 0.f, 0.f};
-                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int o = (4 * ch + r) * kPitch + ((t & 7) << 2);
                     unsigned p01[P], p23[P];
-                    split_pair<P>(x[0][r], x[1][r], p01);
-                    split_pair<P>(x[2][r], x[3][r], p23);
+                    split_pair<P>(xs[4 * i + 0][r], xs[4 * i + 1][r], p01);
+                    split_pair<P>(xs[4 * i + 2][r], xs[4 * i + 3][r], p23);
 #pragma unroll
                     for (int q = 0; q < P; ++q) *reinterpret_cast<uint2*>(img + q * img_stride + o) = make_uint2(p01[q], p23[q]);
                 }
@@ -213,6 +222,9 @@ __device__ __forceinline__ void vm_wait() { asm volatile("s_waitcnt vmcnt(%0)" :
 #endif
 #ifndef SIGMA_GEMM_SLICE_MAJOR
 #define SIGMA_GEMM_SLICE_MAJOR 1           // 0: A/B builds with the tile-major item order for sliced reductions
+#endif
+#ifndef SIGMA_GEMM_FRAG_PIN
+#define SIGMA_GEMM_FRAG_PIN 1              // 0: A/B builds that leave the placement of the fragment reads to the compiler
 #endif
 #ifndef SIGMA_GEMM_ROW_EPILOGUE
 #define SIGMA_GEMM_ROW_EPILOGUE 1          // 0: A/B builds with the direct (dword) epilogue
@@ -293,10 +305,20 @@ gemm_split3_kernel(const GemmArgs g) {
     int pk = 0, ck = 0;
     LoaderA la;
     LoaderB lb_;
+    // operand bases of the producer's next k-step (wave-uniform; advanced by one k-step per request instead of being
+    // rebuilt from the item every time: ~20 SALU of 64-bit multiplies per k-step)
+    const float* pa = nullptr;
+    const float* pb = nullptr;
+    auto seek = [&]() {
+        pa = pit.Ab + (A_KS ? (long)pk * g.lda + pit.m0 : pit.m0 * g.lda + pk);
+        pb = pit.Bb + (B_KS ? (long)pk * g.ldb + pit.n0 : (long)pit.n0 * g.ldb + pk);
+    };
+    const long a_step = A_KS ? (long)kBK * g.lda : kBK, b_step = B_KS ? (long)kBK * g.ldb : kBK;
     if (p_on) {
         decode(p_id, pit); cit = pit; pk = pit.kbeg; ck = pk;
         la.set_tile(g.lda, pit.m0, g.M);
         lb_.set_tile(g.ldb, pit.n0, g.N);
+        seek();
     }
 
     f32x4_t va[kDepth][LoaderA::NV], vb[kDepth][LoaderB::NV];     // the ring
@@ -305,12 +327,12 @@ gemm_split3_kernel(const GemmArgs g) {
         rem_[d_] = 0;
         if (!p_on) return;
         const int rem = pit.kend - pk;
-        const float* abase = pit.Ab + (A_KS ? (long)pk * g.lda + pit.m0 : pit.m0 * g.lda + pk);
-        const float* bbase = pit.Bb + (B_KS ? (long)pk * g.ldb + pit.n0 : (long)pit.n0 * g.ldb + pk);
-        la.issue(VA, abase, rem, g.lda);
-        lb_.issue(VB, bbase, rem, g.ldb);
+        la.issue(VA, pa, rem, g.lda);
+        lb_.issue(VB, pb, rem, g.ldb);
         rem_[d_] = rem < kBK ? rem : kBK;
         pk += kBK;
+        pa += a_step;
+        pb += b_step;
         if (pk >= pit.kend) {
             p_id += gridDim.x;
             p_on = p_id < total;
@@ -318,6 +340,7 @@ gemm_split3_kernel(const GemmArgs g) {
                 decode(p_id, pit); pk = pit.kbeg;
                 la.set_tile(g.lda, pit.m0, g.M);
                 lb_.set_tile(g.ldb, pit.n0, g.N);
+                seek();
             }
         }
     };
@@ -553,27 +576,46 @@ gemm_split3_kernel(const GemmArgs g) {
             lds_barrier();
 #endif
             produce(u, va[u], vb[u]);                  // refill the slot just written to LDS: step s + kDepth
+            // ALL fragments of the k-step are requested up front (16 ds_read_b128 at 128 x 128, 64 VGPRs), pinned in front of
+            // the MFMAs: left to its register heuristics hipcc re-used eight fragment registers and put s_waitcnt
+            // lgkmcnt(0) straight after a read three times per k-block -- the MFMA phase ran at ~55 clocks per MFMA
+            // against 32 (round 6, ISA + the no-memory ablation build).  LDS returns in order, so the compiler's counted
+            // waits release each MFMA as soon as its own two fragments are there.
+            // (three pieces per operand: one k-block at a time -- 24 fragments would not fit beside the accumulators)
+            constexpr int KSN = (SIGMA_GEMM_ABL & 1) ? 0 : kBK / 16;
+            constexpr int KH = P == 2 ? (KSN > 0 ? KSN : 1) : 1;          // k-blocks whose fragments are in registers at once
 #pragma unroll
-            for (int ks = 0; ks < (SIGMA_GEMM_ABL & 1 ? 0 : kBK / 16); ++ks) {
-                bf16x8_t fa[P][TM], fb[P][TN];
+            for (int k0 = 0; k0 < KSN; k0 += KH) {
+                bf16x8_t fa[KH][P][TM], fb[KH][P][TN];
 #pragma unroll
-                for (int q = 0; q < P; ++q) {
+                for (int kh = 0; kh < KH; ++kh) {
 #pragma unroll
-                    for (int i = 0; i < TM; ++i) fa[q][i] = *reinterpret_cast<const bf16x8_t*>(fA + q * BM * kPitch + i * 32 * kPitch + ks * 16);
+                    for (int q = 0; q < P; ++q) {
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) fb[q][j] = *reinterpret_cast<const bf16x8_t*>(fB + q * BN * kPitch + j * 32 * kPitch + ks * 16);
+                        for (int i = 0; i < TM; ++i)
+                            fa[kh][q][i] = *reinterpret_cast<const bf16x8_t*>(fA + q * BM * kPitch + i * 32 * kPitch + (k0 + kh) * 16);
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            fb[kh][q][j] = *reinterpret_cast<const bf16x8_t*>(fB + q * BN * kPitch + j * 32 * kPitch + (k0 + kh) * 16);
+                    }
                 }
-                // piece products with qa + qb < P, smallest first: P = 2: lo*hi, hi*lo, hi*hi (dropped lo*lo ~ 2^-16);
-                // P = 3: the six terms down to 2^-16 (dropped ~ 2^-24: fp32 GEMM accuracy)
+#if SIGMA_GEMM_FRAG_PIN
+                if (P == 2) __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+                for (int kh = 0; kh < KH; ++kh) {
+                    // piece products with qa + qb < P, smallest first: P = 2: lo*hi, hi*lo, hi*hi (dropped lo*lo ~ 2^-16);
+                    // P = 3: the six terms down to 2^-16 (dropped ~ 2^-24: fp32 GEMM accuracy)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
+                    for (int i = 0; i < TM; ++i)
 #pragma unroll
-                        for (int sum = P - 1; sum >= 0; --sum)
+                        for (int j = 0; j < TN; ++j)
 #pragma unroll
-                            for (int qa = sum; qa >= 0; --qa)
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[qa][i], fb[sum - qa][j], acc[i][j], 0, 0, 0);
+                            for (int sum = P - 1; sum >= 0; --sum)
+#pragma unroll
+                                for (int qa = sum; qa >= 0; --qa)
+                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kh][qa][i], fb[kh][sum - qa][j], acc[i][j], 0, 0, 0);
+                }
             }
 #if !(SIGMA_GEMM_ABL & 16)
             lds_barrier();
