@@ -903,6 +903,7 @@ int sigma_scan_debug_read(uint64_t out16[16]) {
     if (e == hipSuccess && out16[15] == 0) e = sigma::bwd4_prof_read(reinterpret_cast<unsigned long long*>(out16));   // quad-row kernel ran
     if (e == hipSuccess && out16[15] == 0) e = sigma::bwdr_prof_read(reinterpret_cast<unsigned long long*>(out16));   // row-lane backward ran
     if (e == hipSuccess && out16[15] == 0) e = sigma::fwdr_prof_read(reinterpret_cast<unsigned long long*>(out16));   // row-lane forward ran
+    if (e == hipSuccess && out16[15] == 0) e = sigma::gemm_prof_read(reinterpret_cast<unsigned long long*>(out16));   // split-operand GEMM ran
     if (e != hipSuccess) return fail(SIGMA_ERR_LAUNCH, "debug read failed: %s", hipGetErrorString(e));
     return SIGMA_OK;
 }

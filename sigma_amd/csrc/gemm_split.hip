@@ -34,7 +34,34 @@
 #define SIGMA_GEMM_ABL 0
 #endif
 
+// Development builds (-DSIGMA_GEMM_PROF=1): clocks per phase of the k-step loop, summed over the waves (sigma_scan_debug_read;
+// tools/diag/gemm_prof.py): 0 wait for operand loads, 1 split + LDS stores, 2 barrier, 3 load issue, 4 fragment reads + MFMA
+// issue, 5 barrier, 6 epilogue + store drain, 7 item switch; 13 tiles, 14 all clocks of the loop, 15 k-steps.  The probes are
+// scheduling barriers and each costs an s_memtime round trip: the instrumented loop runs ~30 % longer.
+#ifndef SIGMA_GEMM_PROF
+#define SIGMA_GEMM_PROF 0
+#endif
+#if SIGMA_GEMM_PROF
+__device__ unsigned long long g_gemm_prof[16];
+#define GPROF(slot) { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_readcyclecounter(); \
+                      prof_[slot] += t_ - tp_; tp_ = t_; __builtin_amdgcn_sched_barrier(0); }
+#else
+#define GPROF(slot)
+#endif
+
 namespace sigma {
+
+#if SIGMA_GEMM_PROF
+hipError_t gemm_prof_read(unsigned long long* out16) {
+    hipError_t e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_gemm_prof), 16 * sizeof(unsigned long long));
+    if (e != hipSuccess) return e;
+    unsigned long long z[16] = {0};
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_gemm_prof), z, sizeof(z));
+}
+#else
+hipError_t gemm_prof_read(unsigned long long* out16) { for (int i = 0; i < 16; ++i) out16[i] = 0; return hipSuccess; }
+#endif
+
 namespace {
 
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
@@ -550,10 +577,16 @@ gemm_split3_kernel(const GemmArgs g) {
     const bool rows_ok = (g.N & 3) == 0 && (g.ldc & 3) == 0 && (reinterpret_cast<uintptr_t>(g.C) & 15) == 0 && (g.sC & 3) == 0 &&
                          !(SIGMA_GEMM_ABL & 4) && SIGMA_GEMM_ROW_EPILOGUE;
 
+#if SIGMA_GEMM_PROF
+    unsigned long long prof_[16] = {0};
+    unsigned long long tp_ = __builtin_readcyclecounter();
+    const unsigned long long t_begin_ = tp_;
+#endif
     while (c_on) {
 #pragma unroll
         for (int u = 0; u < kDepth; ++u) {
             if (!c_on) break;
+            GPROF(7)
             // the loads of slot u are complete when at most the loads of the NEWER stages are outstanding (in-order return)
             {
                 int newer = 0;
@@ -567,15 +600,22 @@ gemm_split3_kernel(const GemmArgs g) {
 #pragma unroll
                 for (int i = 0; i < LoaderB::NV; ++i) asm volatile("" : "+v"(vb[u][i]));
             }
+            GPROF(0)
             const int rem_u = rem_[u];
 #if SIGMA_GEMM_ABL & 16
             asm volatile("" :: "v"(va[u][0]), "v"(vb[u][0]));
 #else
             la.template store<P>(va[u], rem_u, sA, BM * kPitch);
             lb_.template store<P>(vb[u], rem_u, sB, BN * kPitch);
+#if SIGMA_GEMM_PROF
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            GPROF(1)
+#endif
             lds_barrier();
+            GPROF(2)
 #endif
             produce(u, va[u], vb[u]);                  // refill the slot just written to LDS: step s + kDepth
+            GPROF(3)
             // ALL fragments of the k-step are requested up front (16 ds_read_b128 at 128 x 128, 64 VGPRs), pinned in front of
             // the MFMAs: left to its register heuristics hipcc re-used eight fragment registers and put s_waitcnt
             // lgkmcnt(0) straight after a read three times per k-block -- the MFMA phase ran at ~55 clocks per MFMA
@@ -617,8 +657,13 @@ gemm_split3_kernel(const GemmArgs g) {
                                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kh][qa][i], fb[kh][sum - qa][j], acc[i][j], 0, 0, 0);
                 }
             }
+            GPROF(4)
 #if !(SIGMA_GEMM_ABL & 16)
             lds_barrier();
+#endif
+            GPROF(5)
+#if SIGMA_GEMM_PROF
+            prof_[15] += 1;
 #endif
             ck += kBK;
             if (ck >= cit.kend) {                      // tile (slice) complete
@@ -628,12 +673,24 @@ gemm_split3_kernel(const GemmArgs g) {
                 } else if (g.mode == 0) epilogue(cit, [](float* dst, float v) { *dst = v; });
                 else if (g.mode == 1) epilogue(cit, [](float* dst, float v) { *dst += v; });
                 else epilogue(cit, [](float* dst, float v) { atomicAdd(dst, v); });
+#if SIGMA_GEMM_PROF
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // charge the store drain to the epilogue
+                prof_[13] += 1;
+#endif
+                GPROF(6)
                 c_id += gridDim.x;
                 c_on = c_id < total;
                 if (c_on) { decode(c_id, cit); ck = cit.kbeg; init_acc(cit); }
             }
         }
     }
+#if SIGMA_GEMM_PROF
+    prof_[14] = __builtin_readcyclecounter() - t_begin_;
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) atomicAdd(&g_gemm_prof[i], prof_[i]);
+    }
+#endif
 }
 
 template <int BM, int BN, int WM, int WN, bool A_KS, bool B_KS, int P, bool RES>

@@ -82,6 +82,7 @@ hipError_t bwd4_prof_read(unsigned long long* out16);
 hipError_t fwdr_prof_read(unsigned long long* out16);     // development builds (SIGMA_RL_PROF), zeros otherwise
 hipError_t bwdr_prof_read(unsigned long long* out16);
 hipError_t bwdr_chain_timeouts_read(unsigned int* out);   // chained walk: hand-over waits that ran out since the last call
+hipError_t gemm_prof_read(unsigned long long* out16);     // development builds (SIGMA_GEMM_PROF), zeros otherwise
 hipError_t bwd2_prof_read(unsigned long long* out16);     // development builds (SIGMA_BWD2_PROF), zeros otherwise
 hipError_t launch_scan_fwd(const FwdArgs& a, int dtype, int T, bool glds, bool prefetch, hipStream_t stream);
 hipError_t launch_scan_bwd(const BwdArgs& a, int dtype, int T, bool glds, hipStream_t stream);
