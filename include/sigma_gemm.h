@@ -70,6 +70,14 @@ typedef struct sigma_gemm_params {
                               into C with fp32 atomics, as tn does (the CALLER zero-fills C, or passes accumulate = 1):
                               products with few output tiles and a long reduction, e.g. the weight gradient
                               dW = dX^T X with dX held channel-major                                                       */
+    void *workspace;       /* scratch for launches whose work items do not each own their output -- the reduction slices of
+                              tn (and of nn with k_slices), the problems sharing an output under c_mod: with at least
+                              sigma_gemm_workspace_bytes() bytes (16-byte aligned) every item stores its partial result
+                              plainly and a second kernel sums the parts of each output in a fixed order into C (C = or
+                              C += per `accumulate`; no zero fill, deterministic).  NULL / too small: the parts are added
+                              into C with fp32 atomics instead, and the CALLER zero-fills C or passes accumulate = 1
+                              (the atomics were half of a weight-gradient launch: DESIGN.md 4.5, round 6)                */
+    int64_t workspace_bytes;
 } sigma_gemm_params;
 
 /*   sigma_gemm_nt_split3
@@ -88,10 +96,18 @@ int sigma_gemm_nn_split3(const sigma_gemm_params *params, void *stream);
  *       C[i][j] (+)= sum_m A[m][i] * Bt[m][j]                  -- nn.Linear weight gradient dW = dy^T x:
  *       A = dy (M, N_out) with lda, Bt = x (M, K_in) with ldb, C = dW (N_out, K_in); the reduction runs over the
  *       M tokens (params->M), params->N = N_out (rows of C), params->K = K_in (columns of C).  The token
- *       dimension is cut into slices run by different workgroups; partial tiles are summed with fp32 atomics
- *       into C, which the CALLER zero-fills unless accumulate = 1 (run-to-run differences at rounding level,
- *       like the reference's atomicAdd gradients, selective_scan_bwd_kernel.cuh:214-231).                   */
+ *       dimension is cut into slices run by different workgroups.  With params->workspace (see there) the slices'
+ *       partial tiles are stored and summed by a second kernel (C = or C +=, deterministic); without it they are
+ *       summed with fp32 atomics into C, which the CALLER then zero-fills unless accumulate = 1 (run-to-run
+ *       differences at rounding level, like the reference's atomicAdd gradients,
+ *       selective_scan_bwd_kernel.cuh:214-231).                                                             */
 int sigma_gemm_tn_split3(const sigma_gemm_params *params, void *stream);
+
+/*   sigma_gemm_workspace_bytes
+ *       bytes of params->workspace with which the launch described by `params` (form 0 = nt, 1 = nn, 2 = tn) sums its
+ *       partial results in two stages; 0 = every work item owns its output (no scratch needed); -1 = bad arguments.
+ *       params->workspace / workspace_bytes themselves are ignored by the query.                                     */
+int64_t sigma_gemm_workspace_bytes(const sigma_gemm_params *params, int form);
 
 /*   sigma_gemm_selftest
  *       runs the three forms on a small ragged problem whose products are exact in fp32 and compares with host

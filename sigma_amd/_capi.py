@@ -126,6 +126,7 @@ class GemmParams(ctypes.Structure):
         ("c_mod", ctypes.c_int32), ("reserved", ctypes.c_int32),
         ("residual", ctypes.c_void_p), ("residual2", ctypes.c_void_p), ("ldr", ctypes.c_int64), ("strideR", ctypes.c_int64),
         ("Ct", ctypes.c_void_p), ("ldct", ctypes.c_int64), ("t_cols", ctypes.c_int32), ("k_slices", ctypes.c_int32),
+        ("workspace", ctypes.c_void_p), ("workspace_bytes", ctypes.c_int64),
     ]
 
 
@@ -142,7 +143,7 @@ SIGMA_CE_BLOCKS = 1024      # include/sigma_ops.h
 
 # every symbol include/sigma_gemm.h declares
 GEMM_SYMBOLS = ("sigma_gemm_nt_split3", "sigma_gemm_nn_split3", "sigma_gemm_tn_split3")
-GEMM_AUX_SYMBOLS = ("sigma_gemm_selftest",)
+GEMM_AUX_SYMBOLS = ("sigma_gemm_selftest", "sigma_gemm_workspace_bytes")
 
 # every symbol include/sigma_ops.h declares
 OPS_SYMBOLS = ("sigma_dwconv3x3_silu_fwd", "sigma_dwconv3x3_silu_bwd", "sigma_cross_merge_nhwc", "sigma_cross_split_nhwc",
@@ -245,6 +246,8 @@ def load() -> ctypes.CDLL:
         fn.restype = ctypes.c_int
     lib.sigma_gemm_selftest.argtypes = [ctypes.c_void_p]
     lib.sigma_gemm_selftest.restype = ctypes.c_int
+    lib.sigma_gemm_workspace_bytes.argtypes = [P(GemmParams), ctypes.c_int]
+    lib.sigma_gemm_workspace_bytes.restype = ctypes.c_int64
     if lib.sigma_scan_abi_version() != SIGMA_SCAN_ABI_VERSION:
         raise SigmaHipUnavailable(
             f"ABI mismatch: library {lib.sigma_scan_abi_version()} vs binding {SIGMA_SCAN_ABI_VERSION}; rebuild")

@@ -91,6 +91,10 @@ struct GemmArgs {
     // columns [0, t_cols) of the result go TRANSPOSED to Ct[col * ldct + row] (row-contiguous epilogue only, t_cols % 32 == 0);
     // columns >= t_cols to C[row * ldc + col - t_cols]
     float* Ct; long ldct; int t_cols;
+    // nparts > 0: two-stage sums.  C is a scratch buffer of compact (M x N, row stride N) partial results: the item of
+    // slice sl of problem z stores (plainly) into part (z / c_mod) * slices + sl of output z % c_mod (c_mod == 0: output z),
+    // part_stride floats apart; reduce_parts_kernel then sums the parts of every output into the caller's C
+    int nparts; long part_stride;
 };
 
 // P bf16 pieces of two floats (packed pairs): piece[0] = bf16(x), piece[1] = bf16(x - piece[0]), piece[2] = bf16 of the
@@ -317,7 +321,9 @@ gemm_split3_kernel(const GemmArgs g) {
         it.kend = (it.kbeg + g.slice_k < g.K) ? it.kbeg + g.slice_k : g.K;
         it.Ab = g.A + (long)(g.a_mod > 0 ? z % g.a_mod : z) * g.sA;
         it.Bb = g.B + (long)z * g.sB;
-        it.Cb = g.C + (long)(g.c_mod > 0 ? z % g.c_mod : z) * g.sC;
+        const int cidx = g.c_mod > 0 ? z % g.c_mod : z;
+        const long part = (long)cidx * g.nparts + (long)(g.c_mod > 0 ? z / g.c_mod : 0) * g.slices + it.sl;
+        it.Cb = g.C + (g.nparts > 0 ? part * g.part_stride : (long)cidx * g.sC);
         it.r_off = (long)z * g.sR;
     };
 
@@ -751,6 +757,92 @@ hipError_t launch_any(GemmArgs& g, int batch, int pieces, hipStream_t stream) {
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// Second stage of a sliced / shared-output product: C[c] (+)= sum over its nparts compact (M x N) partial results, in a fixed
+// order (deterministic, unlike the atomic sums it replaces).  VEC: four columns per thread (N % 4 == 0, aligned rows).
+// Block = 64 elements x PG part groups: lanes run along the elements (coalesced 16-byte loads), part group y sums the parts
+// y, y + PG, ... (two loads in flight), the groups meet in LDS -- a product with few output elements and hundreds of parts
+// (the 96 x 96 weight gradient of the decoder's last linear: 2304 vectors x 512 parts) still fills the chip.
+template <bool VEC>
+__global__ void __launch_bounds__(1024)
+reduce_parts_kernel(const float* __restrict__ ws, float* __restrict__ C, long M, int N, long ldc, long sC, int nparts, long part_stride, int add) {
+    constexpr int W = VEC ? 4 : 1;
+    typedef float vec_t __attribute__((ext_vector_type(W)));
+    __shared__ vec_t red[16][64];
+    const int PG = blockDim.y, y = threadIdx.y;
+    const long n_el = M * N / W;
+    const long e = (long)blockIdx.x * 64 + threadIdx.x;
+    const bool on = e < n_el;
+    const int c = blockIdx.y;
+    const long flat = (on ? e : 0) * W;
+    const long row = flat / N;
+    const int col = (int)(flat - row * N);
+    const float* __restrict__ src = ws + (long)c * nparts * part_stride + flat;
+    vec_t acc = {};
+    if (on) {
+        int p = y;
+        for (; p + PG < nparts; p += 2 * PG) {
+            const vec_t a0 = *reinterpret_cast<const vec_t*>(src + (long)p * part_stride);
+            const vec_t a1 = *reinterpret_cast<const vec_t*>(src + (long)(p + PG) * part_stride);
+            acc += a0 + a1;
+        }
+        if (p < nparts) acc += *reinterpret_cast<const vec_t*>(src + (long)p * part_stride);
+    }
+    if (PG > 1) {
+        red[y][threadIdx.x] = acc;
+        __syncthreads();
+        if (y == 0)
+            for (int q = 1; q < PG; ++q) acc += red[q][threadIdx.x];
+    }
+    if (on && y == 0) {
+        vec_t* __restrict__ dst = reinterpret_cast<vec_t*>(C + (long)c * sC + row * ldc + col);
+        if (add) acc += *dst;
+        *dst = acc;
+    }
+}
+
+// bytes of scratch the two-stage sum of a launch needs (0: a single part per output -- no second stage)
+int64_t parts_bytes(const GemmArgs& g, int batch) {
+    const int per_out = g.slices * (g.c_mod > 0 ? batch / g.c_mod : 1);
+    if (per_out <= 1) return 0;
+    if (g.c_mod > 0 && batch % g.c_mod != 0) return 0;          // ragged groups keep the atomic path
+    const long outs = g.c_mod > 0 ? g.c_mod : batch;
+    return (int64_t)outs * per_out * g.M * g.N * (int64_t)sizeof(float);
+}
+
+// A launch whose items do not each own their output (reduction slices, problems sharing an output): with enough scratch
+// (ws / ws_bytes from the caller) as plain partial stores + reduce_parts_kernel, otherwise with fp32 atomics into C (which
+// the caller then zero-filled or accumulates into).  Round 6: the 64 dword atomics per thread and item were HALF of a
+// weight-gradient launch (profiles/r06_gemm_phases.jsonl) and its shape-independent floor of ~50 us.
+template <bool A_KS, bool B_KS>
+hipError_t launch_summed(GemmArgs& g, int batch, int pieces, void* ws, int64_t ws_bytes, bool accumulate, hipStream_t stream) {
+    const int64_t need = parts_bytes(g, batch);
+    if (need == 0 || ws == nullptr || ws_bytes < need || !aligned16(ws)) {
+        g.mode = 2;
+        g.nparts = 0;
+        return launch_any<A_KS, B_KS>(g, batch, pieces, stream);
+    }
+    float* const C = g.C;
+    const long ldc = g.ldc, sC = g.sC;
+    const int outs = g.c_mod > 0 ? g.c_mod : batch;
+    g.nparts = g.slices * (g.c_mod > 0 ? batch / g.c_mod : 1);
+    g.part_stride = g.M * g.N;
+    g.C = static_cast<float*>(ws);
+    g.ldc = g.N;
+    g.sC = 0;
+    g.mode = 0;
+    hipError_t e = launch_any<A_KS, B_KS>(g, batch, pieces, stream);
+    if (e != hipSuccess) return e;
+    const bool vec = (g.N & 3) == 0 && (ldc & 3) == 0 && (sC & 3) == 0 && aligned16(C);
+    const long n_el = g.M * g.N / (vec ? 4 : 1);
+    const long blocks = (n_el + 63) / 64;
+    int pg = 1;                                          // part groups per block: until ~2 waves per SIMD are in flight
+    while (pg < 16 && 2 * pg <= g.nparts && blocks * outs * pg < 2048) pg *= 2;
+    const dim3 grid((unsigned)blocks, (unsigned)outs), block(64, pg);
+    if (vec) hipLaunchKernelGGL(reduce_parts_kernel<true>, grid, block, 0, stream, (const float*)g.C, C, g.M, g.N, ldc, sC, g.nparts, g.part_stride, accumulate ? 1 : 0);
+    else hipLaunchKernelGGL(reduce_parts_kernel<false>, grid, block, 0, stream, (const float*)g.C, C, g.M, g.N, ldc, sC, g.nparts, g.part_stride, accumulate ? 1 : 0);
+    return hipGetLastError();
+}
+
 int fill_common(const sigma_gemm_params* p, GemmArgs& g) {
     if (!p || !p->A || !p->Bt || !p->C) return SIGMA_OPS_ERR_ARG;
     if (p->M < 0 || p->N < 0 || p->K < 0 || p->batch < 0) return SIGMA_OPS_ERR_ARG;
@@ -766,6 +858,8 @@ int fill_common(const sigma_gemm_params* p, GemmArgs& g) {
     g.mode = p->accumulate ? 1 : 0;
     g.R = p->residual; g.R2 = p->residual ? p->residual2 : nullptr; g.ldr = p->ldr; g.sR = p->strideR;
     g.Ct = nullptr; g.ldct = 0; g.t_cols = 0;
+    g.nparts = 0; g.part_stride = 0;
+    if (p->workspace_bytes < 0 || (p->workspace_bytes > 0 && !p->workspace)) return SIGMA_OPS_ERR_ARG;
     if (!p->residual && p->residual2) return SIGMA_OPS_ERR_ARG;
     if (p->residual && (p->ldr <= 0 || p->M * p->ldr >= 0x7fffffffL)) return SIGMA_OPS_ERR_ARG;
     if (p->c_mod < 0 || p->reserved != 0) return SIGMA_OPS_ERR_ARG;
@@ -775,51 +869,61 @@ int fill_common(const sigma_gemm_params* p, GemmArgs& g) {
 }  // namespace
 }  // namespace sigma
 
-extern "C" int sigma_gemm_nt_split3(const sigma_gemm_params* p, void* stream) {
-    sigma::GemmArgs g;
-    int rc = sigma::fill_common(p, g);
+namespace sigma {
+namespace {
+
+// The three forms: argument checks and launch geometry (shared by the entry points and sigma_gemm_workspace_bytes).
+// `summed`: the items of the launch do not each own their output (launch_summed); `empty`: nothing to do.
+struct Planned { GemmArgs g; int batch; bool summed; bool empty; };
+
+int plan_nt(const sigma_gemm_params* p, Planned& pl) {
+    GemmArgs& g = pl.g;
+    int rc = fill_common(p, g);
     if (rc) return rc;
     if (p->K % 4 != 0) return SIGMA_OPS_ERR_ARG;
-    const int batch = p->batch > 0 ? p->batch : 1;
-    if (p->M == 0 || p->N == 0) return SIGMA_OPS_OK;
+    pl.batch = p->batch > 0 ? p->batch : 1;
+    pl.summed = false;
+    pl.empty = p->M == 0 || p->N == 0;
+    if (pl.empty) return SIGMA_OPS_OK;
     g.M = p->M; g.N = p->N; g.K = p->K;
     if (p->K == 0) return SIGMA_OPS_ERR_ARG;
     g.slice_k = (p->K + 31) / 32 * 32;
     g.a_mod = p->a_mod;
-    if (p->c_mod > 0 && batch > p->c_mod) {          // several problems per output: summed with atomics
+    if (p->c_mod > 0 && pl.batch > p->c_mod) {       // several problems per output: summed
         if (p->residual || p->bias) return SIGMA_OPS_ERR_ARG;
-        g.c_mod = p->c_mod; g.mode = 2;
+        g.c_mod = p->c_mod; pl.summed = true;
     } else if (p->c_mod > 0) g.c_mod = p->c_mod;
     if (p->t_cols != 0) {                                // transposed column range: row-contiguous epilogue, plain stores only
-        if (p->t_cols < 0 || p->t_cols > p->N || p->t_cols % 32 != 0 || !p->Ct || !sigma::aligned16(p->Ct) || p->ldct % 4 != 0 ||
-            p->ldct < p->M || p->M % 4 != 0 || p->N % 4 != 0 || p->ldc % 4 != 0 || !sigma::aligned16(p->C) || batch != 1 ||
-            p->accumulate || p->residual || g.mode != 0 || !SIGMA_GEMM_ROW_EPILOGUE)
+        if (p->t_cols < 0 || p->t_cols > p->N || p->t_cols % 32 != 0 || !p->Ct || !aligned16(p->Ct) || p->ldct % 4 != 0 ||
+            p->ldct < p->M || p->M % 4 != 0 || p->N % 4 != 0 || p->ldc % 4 != 0 || !aligned16(p->C) || pl.batch != 1 ||
+            p->accumulate || p->residual || pl.summed || !SIGMA_GEMM_ROW_EPILOGUE)
             return SIGMA_OPS_ERR_ARG;
         g.Ct = p->Ct; g.ldct = p->ldct; g.t_cols = p->t_cols;
     }
-    hipError_t e = sigma::launch_any<false, false>(g, batch, p->pieces, static_cast<hipStream_t>(stream));
-    return e == hipSuccess ? SIGMA_OPS_OK : SIGMA_OPS_ERR_LAUNCH;
+    return SIGMA_OPS_OK;
 }
 
-extern "C" int sigma_gemm_nn_split3(const sigma_gemm_params* p, void* stream) {
+int plan_nn(const sigma_gemm_params* p, Planned& pl) {
     // C = A B with B = (K, N) row-major (params->Bt, row stride ldb): the B operand's reduction index is its slow index
-    sigma::GemmArgs g;
-    int rc = sigma::fill_common(p, g);
+    GemmArgs& g = pl.g;
+    int rc = fill_common(p, g);
     if (rc) return rc;
     if (p->K % 4 != 0 || p->N % 4 != 0) return SIGMA_OPS_ERR_ARG;
-    const int batch = p->batch > 0 ? p->batch : 1;
-    if (p->M == 0 || p->N == 0) return SIGMA_OPS_OK;
+    pl.batch = p->batch > 0 ? p->batch : 1;
+    pl.summed = false;
+    pl.empty = p->M == 0 || p->N == 0;
+    if (pl.empty) return SIGMA_OPS_OK;
     g.M = p->M; g.N = p->N; g.K = p->K;
     if (p->K == 0) return SIGMA_OPS_ERR_ARG;
     g.slice_k = (p->K + 31) / 32 * 32;
     g.a_mod = p->a_mod;
-    if (p->c_mod > 0 && batch > p->c_mod) {          // several problems per output: summed with atomics
+    if (p->c_mod > 0 && pl.batch > p->c_mod) {       // several problems per output: summed
         if (p->residual || p->bias) return SIGMA_OPS_ERR_ARG;
-        g.c_mod = p->c_mod; g.mode = 2;
+        g.c_mod = p->c_mod; pl.summed = true;
     } else if (p->c_mod > 0) g.c_mod = p->c_mod;
-    if (p->k_slices == 1 && g.mode != 2 && !p->residual && !p->bias && batch == 1) {
-        // few output tiles, long reduction: slices summed with atomics, one round of resident workgroups (as tn)
-        const int bn = sigma::pick_bn(g.N);
+    if (p->k_slices == 1 && !pl.summed && !p->residual && !p->bias && pl.batch == 1) {
+        // few output tiles, long reduction: reduction slices, one round of resident workgroups (as tn)
+        const int bn = pick_bn(g.N);
         const long tiles = ((g.M + 127) / 128) * ((g.N + bn - 1) / bn);
         const long steps = (p->K + 31) / 32;
         long want = 512 / (tiles > 0 ? tiles : 1);
@@ -828,31 +932,32 @@ extern "C" int sigma_gemm_nn_split3(const sigma_gemm_params* p, void* stream) {
             const long per = (steps + want - 1) / want;
             g.slice_k = (int)(per * 32);
             g.slices = (int)((steps + per - 1) / per);
-            if (g.slices > 1) g.mode = 2;
+            if (g.slices > 1) pl.summed = true;
         }
     }
-    hipError_t e = sigma::launch_any<false, true>(g, batch, p->pieces, static_cast<hipStream_t>(stream));
-    return e == hipSuccess ? SIGMA_OPS_OK : SIGMA_OPS_ERR_LAUNCH;
+    return SIGMA_OPS_OK;
 }
 
-extern "C" int sigma_gemm_tn_split3(const sigma_gemm_params* p, void* stream) {
+int plan_tn(const sigma_gemm_params* p, Planned& pl) {
     // C (N_out x K_in) (+)= A^T B with A = (M, N_out), Bt = (M, K_in): both operands have the reduction (token) index
     // as the slow memory index.  Kernel view: rows of C = N_out, columns = K_in, reduction = M.
-    sigma::GemmArgs g;
-    int rc = sigma::fill_common(p, g);
+    GemmArgs& g = pl.g;
+    int rc = fill_common(p, g);
     if (rc) return rc;
     if (p->N % 4 != 0 || p->K % 4 != 0) return SIGMA_OPS_ERR_ARG;
     if (p->c_mod != 0 || p->residual) return SIGMA_OPS_ERR_ARG;      // nt / nn only
-    const int batch = p->batch > 0 ? p->batch : 1;
-    if (p->N == 0 || p->K == 0 || p->M == 0) return SIGMA_OPS_OK;
+    pl.batch = p->batch > 0 ? p->batch : 1;
+    pl.summed = false;
+    pl.empty = p->N == 0 || p->K == 0 || p->M == 0;
+    if (pl.empty) return SIGMA_OPS_OK;
     g.M = p->N; g.N = p->K; g.K = (int)p->M;
     if (p->M > 0x7fffff00L) return SIGMA_OPS_ERR_ARG;
-    // reduction slices: enough workgroups for ~3 per CU, each slice a multiple of 32 tokens, at least 8 k-steps long
-    const int bn = sigma::pick_bn(g.N);
-    const long tiles = (long)batch * ((g.M + 127) / 128) * ((g.N + bn - 1) / bn);
+    // reduction slices: each a multiple of 32 tokens and at least 8 k-steps long, and no more items than ONE round of
+    // resident workgroups (2 per CU): 768 items on 512 slots ran 1.5 rounds (round 6: 144 -> 132 us at enc_s2_in_proj,
+    // 92 -> 71 us at the small shapes)
+    const int bn = pick_bn(g.N);
+    const long tiles = (long)pl.batch * ((g.M + 127) / 128) * ((g.N + bn - 1) / bn);
     const long steps = (p->M + 31) / 32;
-    // ... but no more items than ONE round of resident workgroups (2 per CU): 768 items on 512 slots ran 1.5 rounds and paid
-    // 50 % more atomic tile additions than 504 (round 6: 144 -> 132 us at enc_s2_in_proj, 92 -> 71 us at the small shapes)
     static const long target_items = [] { const char* e = getenv("SIGMA_GEMM_TN_ITEMS"); const long v = e ? atol(e) : 0; return v > 0 ? v : 512L; }();
     long want = target_items / tiles;
     if (want > steps / 8) want = steps / 8;
@@ -860,9 +965,45 @@ extern "C" int sigma_gemm_tn_split3(const sigma_gemm_params* p, void* stream) {
     const long per = (steps + want - 1) / want;
     g.slice_k = (int)(per * 32);
     g.slices = (int)((steps + per - 1) / per);
-    if (g.slices > 1) g.mode = 2;                     // caller zero-filled C (or accumulates)
-    hipError_t e = sigma::launch_any<true, true>(g, batch, p->pieces, static_cast<hipStream_t>(stream));
+    pl.summed = g.slices > 1;
+    return SIGMA_OPS_OK;
+}
+
+template <bool A_KS, bool B_KS>
+int run_planned(const sigma_gemm_params* p, Planned& pl, void* stream) {
+    if (pl.empty) return SIGMA_OPS_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    hipError_t e = pl.summed ? launch_summed<A_KS, B_KS>(pl.g, pl.batch, p->pieces, p->workspace, p->workspace_bytes, p->accumulate != 0, s)
+                             : launch_any<A_KS, B_KS>(pl.g, pl.batch, p->pieces, s);
     return e == hipSuccess ? SIGMA_OPS_OK : SIGMA_OPS_ERR_LAUNCH;
+}
+
+}  // namespace
+}  // namespace sigma
+
+extern "C" int sigma_gemm_nt_split3(const sigma_gemm_params* p, void* stream) {
+    sigma::Planned pl;
+    const int rc = sigma::plan_nt(p, pl);
+    return rc ? rc : sigma::run_planned<false, false>(p, pl, stream);
+}
+
+extern "C" int sigma_gemm_nn_split3(const sigma_gemm_params* p, void* stream) {
+    sigma::Planned pl;
+    const int rc = sigma::plan_nn(p, pl);
+    return rc ? rc : sigma::run_planned<false, true>(p, pl, stream);
+}
+
+extern "C" int sigma_gemm_tn_split3(const sigma_gemm_params* p, void* stream) {
+    sigma::Planned pl;
+    const int rc = sigma::plan_tn(p, pl);
+    return rc ? rc : sigma::run_planned<true, true>(p, pl, stream);
+}
+
+extern "C" int64_t sigma_gemm_workspace_bytes(const sigma_gemm_params* p, int form) {
+    sigma::Planned pl;
+    const int rc = form == 0 ? sigma::plan_nt(p, pl) : form == 1 ? sigma::plan_nn(p, pl) : form == 2 ? sigma::plan_tn(p, pl) : SIGMA_OPS_ERR_ARG;
+    if (rc) return -1;
+    return (pl.empty || !pl.summed) ? 0 : sigma::parts_bytes(pl.g, pl.batch);
 }
 
 // Self test: the three kernel forms on operands whose products and sums are exact in fp32 (integers of small magnitude:

@@ -85,10 +85,34 @@ def selftest(device=None) -> None:
     _selftest(torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device))
 
 
+_FORMS = {"sigma_gemm_nt_split3": 0, "sigma_gemm_nn_split3": 1, "sigma_gemm_tn_split3": 2}
+# A/B knob: SIGMA_GEMM_TWO_STAGE=0 keeps the round-5 path -- atomic sums into an output the wrappers zero-fill first
+_TWO_STAGE = os.environ.get("SIGMA_GEMM_TWO_STAGE", "1") != "0"
+
+
+def _atomic_path(out: torch.Tensor, accumulate: bool) -> bool:
+    """A/B path only: the output of a possibly sliced launch is zero-filled here and then added into"""
+    if not accumulate:
+        out.zero_()
+    return True
+
+
 def _run(name, p, dev):
     _selftest(dev)
+    lib = _capi.load()
+    # Launches whose work items do not each own their output (reduction slices of a weight gradient, problems sharing an
+    # output) get the scratch for the two-stage sum: partial results stored plainly + one reduce kernel, instead of 64
+    # dword atomics per thread and item (half of such a launch, round 6) -- and the output needs no zero fill.  The
+    # buffer comes from torch's caching allocator and goes back when this call returns: stream-ordered, so the kernels
+    # enqueued here finish with it before a later allocation on this stream can reuse it.
+    need = int(lib.sigma_gemm_workspace_bytes(ctypes.byref(p), _FORMS[name])) if _TWO_STAGE else 0   # < 0: bad arguments -- the call below says so
+    ws = None
+    if need > 0:
+        ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        p.workspace, p.workspace_bytes = ws.data_ptr(), need
     with torch.cuda.device(dev):
-        rc = getattr(_capi.load(), name)(ctypes.byref(p), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+        rc = getattr(lib, name)(ctypes.byref(p), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    del ws
     if rc != 0:
         raise RuntimeError(f"{name} failed (sigma_ops status {rc}): M={p.M} N={p.N} K={p.K} lda={p.lda} ldb={p.ldb}")
 
@@ -155,7 +179,7 @@ def nn_ok(a: torch.Tensor, b: torch.Tensor) -> bool:
 def gemm_nn(a: torch.Tensor, b: torch.Tensor, out=None, accumulate=False, pieces: int = 2, k_slices: bool = False) -> torch.Tensor:
     """out (M, N) (+)= a (M, K) @ b (K, N), b read row-major in place.  ``k_slices``: few output tiles and a long reduction
     (a weight gradient whose left operand is held channel-major): the kernel may cut K into slices summed with fp32 atomics;
-    ``out`` is then zero-filled here unless ``accumulate``."""
+    (two-stage sum through scratch: ``out`` is written, or added to with ``accumulate``)."""
     _check2d(a, b)
     M, K = a.shape
     N = b.shape[1]
@@ -163,14 +187,16 @@ def gemm_nn(a: torch.Tensor, b: torch.Tensor, out=None, accumulate=False, pieces
         raise RuntimeError("gemm_nn: operands must be (M, K) and (K, N) with K % 4 == 0, N % 4 == 0 and 16-byte aligned rows")
     _check_aux("gemm_nn", None, out, N, a.device)
     if out is None:
-        out = (torch.zeros if k_slices else torch.empty)((M, N), device=a.device, dtype=torch.float32)
+        if accumulate:
+            raise RuntimeError("gemm_nn: accumulate needs out")
+        out = torch.empty((M, N), device=a.device, dtype=torch.float32)
     elif out.stride(1) != 1 or tuple(out.shape) != (M, N):
         raise RuntimeError("gemm_nn: out must be (M, N) with contiguous rows")
-    elif k_slices and not accumulate:
-        out.zero_()
     if M and N:
+        if k_slices and not _TWO_STAGE:
+            accumulate = _atomic_path(out, accumulate)
         _run("sigma_gemm_nn_split3", _params(M, N, K, a, b, out, None, a.stride(0), b.stride(0), out.stride(0),
-                                             accumulate or k_slices, pieces=pieces, k_slices=1 if k_slices else 0), a.device)
+                                             accumulate, pieces=pieces, k_slices=1 if k_slices else 0), a.device)
     return out
 
 
@@ -191,13 +217,14 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, out=None, accumulate=False, pieces
             return torch.zeros((N, K), device=a.device, dtype=torch.float32)
         return out if accumulate else out.zero_()
     if out is None:
-        out = torch.zeros((N, K), device=a.device, dtype=torch.float32)      # slices are summed with atomics
+        if accumulate:
+            raise RuntimeError("gemm_tn: accumulate needs out")
+        out = torch.empty((N, K), device=a.device, dtype=torch.float32)      # written by the kernel(s): slices are summed in two stages
     elif out.stride(1) != 1 or tuple(out.shape) != (N, K):
         raise RuntimeError("gemm_tn: out must be (N, K) with contiguous rows")
-    elif not accumulate:
-        out.zero_()
-        accumulate = True
     if N and K:
+        if not _TWO_STAGE:
+            accumulate = _atomic_path(out, accumulate)
         _run("sigma_gemm_tn_split3", _params(M, N, K, a, b, out, None, a.stride(0), b.stride(0), out.stride(0), accumulate, pieces=pieces), a.device)
     return out
 
@@ -243,10 +270,11 @@ def bgemm_nn(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, residual=None,
     return out
 
 
-def bgemm_nt_sum(a: torch.Tensor, bt: torch.Tensor, out: torch.Tensor, pieces: int = 2) -> torch.Tensor:
-    """out[z % Zc] (M, N) += a[z] (M, K) @ bt[z] (N, K)^T summed over the problems that share an output (fp32 atomics):
-    out (Zc, M, N) contiguous per problem, ZERO-FILLED (or holding a value to add to) by the caller; Zc divides Z.  The
-    weight gradients of the stacked projections summed over the batch."""
+def bgemm_nt_sum(a: torch.Tensor, bt: torch.Tensor, out: torch.Tensor, pieces: int = 2, accumulate: bool = True) -> torch.Tensor:
+    """out[z % Zc] (M, N) (+)= a[z] (M, K) @ bt[z] (N, K)^T summed over the problems that share an output (two-stage sum
+    through scratch, fixed order): out (Zc, M, N) contiguous per problem; ``accumulate`` (default, the round-4 contract):
+    added to what out holds, else out is overwritten and needs no zero fill; Zc divides Z.  The weight gradients of the
+    stacked projections summed over the batch."""
     _check3d("bgemm_nt_sum", a, bt, out)
     Z, M, K = a.shape
     Zb, N, Kb = bt.shape
@@ -254,7 +282,9 @@ def bgemm_nt_sum(a: torch.Tensor, bt: torch.Tensor, out: torch.Tensor, pieces: i
     if Zb != Z or Kb != K or tuple(out.shape[1:]) != (M, N) or Z % max(Zc, 1) != 0 or K % 4 != 0:
         raise RuntimeError(f"bgemm_nt_sum: shapes a {tuple(a.shape)} bt {tuple(bt.shape)} out {tuple(out.shape)}")
     if Z and M and N:
-        _run("sigma_gemm_nt_split3", _params(M, N, K, a, bt, out, None, a.stride(1), bt.stride(1), out.stride(1), True, batch=Z,
+        if not _TWO_STAGE:
+            accumulate = _atomic_path(out, accumulate)
+        _run("sigma_gemm_nt_split3", _params(M, N, K, a, bt, out, None, a.stride(1), bt.stride(1), out.stride(1), accumulate, batch=Z,
                                              sA=a.stride(0), sB=bt.stride(0), sC=out.stride(0), c_mod=Zc, pieces=pieces), a.device)
     return out
 

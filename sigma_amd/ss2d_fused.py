@@ -501,8 +501,8 @@ class SS2DCoreFn(torch.autograd.Function):
             rev_mask=_REV_MASK, u_gshift=1, dout_gshift=1, dB_out=dp4[:, :, R:R + N], dC_out=dp4[:, :, R + N:], param_swap=1,
             ckpt_pitch=ctx.pitch)
         ddelta4 = ddelta.view(B, 4, d, L)
-        # weight gradients computed by the kernels: ONE zero fill, the sum over the batch inside the kernels (atomics)
-        wg = torch.zeros(4 * d * R + 4 * c * d, device=xs2.device, dtype=torch.float32) if (own["xw"] or own["dw"]) else None
+        # weight gradients computed by the kernels: the sum over the batch in two stages inside the library (no zero fill)
+        wg = torch.empty(4 * d * R + 4 * c * d, device=xs2.device, dtype=torch.float32) if (own["xw"] or own["dw"]) else None
         # dt_proj: delta = dtw @ p4[:R]
         if own["dd"]:
             _gemm.bgemm_nn(dtw.transpose(1, 2).contiguous(), ddelta.view(4 * B, d, L), dp4.view(4 * B, c, L)[:, :R], pieces=_XPROJ)
@@ -510,7 +510,7 @@ class SS2DCoreFn(torch.autograd.Function):
             dp4[:, :, :R] = torch.matmul(dtw.transpose(1, 2).unsqueeze(0), ddelta4)
         if own["dw"]:
             d_dtw = wg[:4 * d * R].view(4, d, R)
-            _gemm.bgemm_nt_sum(ddelta.view(4 * B, d, L), p4.view(4 * B, c, L)[:, :R], d_dtw, pieces=_XPROJ)
+            _gemm.bgemm_nt_sum(ddelta.view(4 * B, d, L), p4.view(4 * B, c, L)[:, :R], d_dtw, pieces=_XPROJ, accumulate=False)
         else:
             d_dtw = torch.matmul(ddelta4, p4[:, :, :R].transpose(-1, -2)).sum(0)   # (4, d, R)
         # x_proj: p = Wst @ xs2; its input gradient joins the scan's du of both directions of an order
@@ -525,7 +525,7 @@ class SS2DCoreFn(torch.autograd.Function):
             _pair_sum_add(du, dxs2, B * 2, d * L)                              # + du of both directions of an order
         if own["xw"]:
             dWst = wg[4 * d * R:].view(2, 2 * c, d)
-            _gemm.bgemm_nt_sum(dp4.view(2 * B, 2 * c, L), xs2.view(2 * B, d, L), dWst, pieces=_XPROJ)
+            _gemm.bgemm_nt_sum(dp4.view(2 * B, 2 * c, L), xs2.view(2 * B, d, L), dWst, pieces=_XPROJ, accumulate=False)
         else:
             dWst = torch.matmul(dp2, xs2.transpose(-1, -2)).sum(0)             # (2, 2c, d)
         d_xproj = _perm4(dWst.view(4, c, d))                                   # the permutation is its own inverse

@@ -30,7 +30,7 @@ def test_exports_every_declared_symbol():
     for name in declared_ops:
         assert getattr(lib, name) is not None
     gemm = open(os.path.join(ROOT, "include", "sigma_gemm.h")).read()
-    declared_gemm = set(re.findall(r"^\s*int\s+(sigma_\w+)\s*\(", gemm, flags=re.M))
+    declared_gemm = set(re.findall(r"^\s*(?:int|int64_t)\s+(sigma_\w+)\s*\(", gemm, flags=re.M))
     assert declared_gemm == set(_capi.GEMM_SYMBOLS) | set(_capi.GEMM_AUX_SYMBOLS), declared_gemm ^ set(_capi.GEMM_SYMBOLS)
     for name in declared_gemm:
         assert getattr(lib, name) is not None

@@ -324,3 +324,64 @@ def test_gemm_nn_with_a_sliced_reduction_against_fp64(shape):
     acc = _rand(M, N, seed=43)
     got = gemm.gemm_nn(a, b, out=acc.clone(), accumulate=True, k_slices=True)
     _assert_close(got, want + acc.double(), bound + acc.double().abs(), "nn sliced accumulate")
+
+
+@pytest.mark.parametrize("shape", [(19200, 1536, 384), (19200, 384, 768), (4800, 96, 192), (1001, 68, 36)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_sliced_reductions_sum_in_two_stages_without_a_zero_fill(shape):
+    """Round 6: the reduction slices of a weight gradient are stored as partial results in scratch and summed by a second
+    kernel (sigma_gemm_workspace_bytes / params.workspace): the output needs no zero fill (here it holds NaN), two runs
+    agree bit for bit, `accumulate` adds, and a caller WITHOUT scratch still gets the atomic sums into a zero-filled C."""
+    import ctypes
+    from sigma_amd import _capi, gemm
+    M, Nout, Kin = shape
+    dy, x = _rand(M, Nout, seed=8, scale=0.1), _rand(M, Kin, seed=9)
+    want = dy.double().t() @ x.double()
+    bound = _bound(dy.double().t(), x.double())
+    out = torch.full((Nout, Kin), float("nan"), device=DEV)
+    gemm.gemm_tn(dy, x, out=out)
+    _assert_close(out, want, bound, "tn into NaN")
+    again = torch.full((Nout, Kin), float("nan"), device=DEV)
+    gemm.gemm_tn(dy, x, out=again)
+    assert torch.equal(out, again)                              # fixed summation order
+    big = torch.full((2 * Nout, Kin), 3.0, device=DEV)          # a row-slice view of a larger gradient tensor
+    gemm.gemm_tn(dy, x, out=big[Nout:])
+    assert torch.equal(big[Nout:], out) and float((big[:Nout] - 3.0).abs().max()) == 0.0
+    # the C ABI without scratch: atomics into a zero-filled C
+    p = gemm._params(M, Nout, Kin, dy, x, out, None, dy.stride(0), x.stride(0), out.stride(0), False)
+    need = int(_capi.load().sigma_gemm_workspace_bytes(ctypes.byref(p), 2))
+    assert need >= 0
+    out.zero_()
+    with torch.cuda.device(dy.device):
+        rc = _capi.load().sigma_gemm_tn_split3(ctypes.byref(p), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+    assert rc == 0
+    _assert_close(out, want, bound, "tn atomics")
+    if need > 0:                                                 # scratch one byte short: refused as scratch, atomics again
+        ws = torch.empty(need, dtype=torch.uint8, device=DEV)
+        p.workspace, p.workspace_bytes = ws.data_ptr(), need - 1
+        out.zero_()
+        with torch.cuda.device(dy.device):
+            assert _capi.load().sigma_gemm_tn_split3(ctypes.byref(p), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+        _assert_close(out, want, bound, "tn short scratch")
+        p.workspace, p.workspace_bytes = None, 16                # bytes without a pointer
+        with torch.cuda.device(dy.device):
+            assert _capi.load().sigma_gemm_tn_split3(ctypes.byref(p), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)) != 0
+
+
+def test_shared_outputs_sum_in_two_stages():
+    """bgemm_nt_sum (weight gradients of the stacked projections summed over the batch): overwrite into NaN, accumulate,
+    bit-identical repeats; a ragged problem count per output keeps the atomic path (zero-filled / accumulated C)"""
+    from sigma_amd import gemm
+    B, d, c, L = 8, 192, 16, 1200
+    dp, xs = _rand(2 * B, 2 * c, L, seed=51), _rand(2 * B, d, L, seed=52)
+    want = torch.matmul(dp.double(), xs.double().transpose(-1, -2)).view(B, 2, 2 * c, d).sum(0)
+    bound = torch.matmul(dp.double().abs(), xs.double().abs().transpose(-1, -2)).view(B, 2, 2 * c, d).sum(0)
+    out = torch.full((2, 2 * c, d), float("nan"), device=DEV)
+    gemm.bgemm_nt_sum(dp, xs, out, accumulate=False)
+    _assert_close(out, want, bound, "nt_sum overwrite")
+    again = torch.full((2, 2 * c, d), float("nan"), device=DEV)
+    gemm.bgemm_nt_sum(dp, xs, again, accumulate=False)
+    assert torch.equal(out, again)
+    acc = torch.ones(2, 2 * c, d, device=DEV)
+    gemm.bgemm_nt_sum(dp, xs, acc)
+    _assert_close(acc, want + 1.0, bound + 1.0, "nt_sum accumulate")
