@@ -712,6 +712,9 @@ hipError_t launch_cfg(const GemmArgs& g, int batch, hipStream_t stream) {
         int n = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_split3_kernel<BM, BN, WM, WN, A_KS, B_KS, P, RES>, 256, 0) != hipSuccess || n < 1) n = 2;
         per_cu = n > 4 ? 4 : n;
+#ifdef SIGMA_GEMM_MAX_PER_CU
+        if (per_cu > SIGMA_GEMM_MAX_PER_CU) per_cu = SIGMA_GEMM_MAX_PER_CU;     // A/B builds: resident workgroups per CU capped
+#endif
     }
     long grid = 256L * per_cu;
     if (grid > items) grid = items;
@@ -721,6 +724,9 @@ hipError_t launch_cfg(const GemmArgs& g, int batch, hipStream_t stream) {
 
 // tile width for N columns: 128 unless a narrower tile wastes less ((N = 96, 192: 96-wide tiles are exact)
 int pick_bn(int N) {
+#ifdef SIGMA_GEMM_FORCE_BN
+    return SIGMA_GEMM_FORCE_BN;                         // A/B builds: one tile width for every problem
+#endif
     if (N % 128 == 0) return 128;
     if (N % 96 == 0) return 96;
     if (N <= 64) return 64;

@@ -36,7 +36,7 @@ def main():
         own = {
             "x_proj": lambda: gemm.bgemm_nn(Wst, xs.view(2 * B, d, L), p4.view(2 * B, 2 * c, L)),
             "x_dgrad+du": lambda: gemm.bgemm_nn(WstT, dp4.view(2 * B, 2 * c, L), dxs.view(2 * B, d, L), residual=du3[:, 0], residual2=du3[:, 1]),
-            "x_wgrad": lambda: gemm.bgemm_nt_sum(dp4.view(2 * B, 2 * c, L), xs.view(2 * B, d, L), dW),
+            "x_wgrad": lambda: gemm.bgemm_nt_sum(dp4.view(2 * B, 2 * c, L), xs.view(2 * B, d, L), dW, accumulate=False),
         }
         if R % 4 == 0:
             own.update({
