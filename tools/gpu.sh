@@ -7,7 +7,7 @@
 #   pmc <tag> <shape> [scan_bench args]   FETCH_SIZE / WRITE_SIZE passes of one scan launch shape (tools/gpu_pmc.sh)
 #   scanbench <tag> <shapes> [lib suffixes...]   tools/scan_bench.py on the shapes, once per library variant ("" = the product build)
 #   extras [tag]         forward-only lines, sigma_base 720x1280, batch-8 HIP graph, step without the TunableOp table
-#   final [n]            end-of-round evidence on the final code: driver x n, bench, trace, pmc of the dominant launch
+#   final [n]            end-of-round evidence on the final code: driver x n, bench, trace, pmc of the dominant launch, round-5 tree on the same box
 set -u
 step=${1:-driver}
 shift || true
@@ -84,6 +84,19 @@ final)
   # the driver's N-rank launch line with one rank (launch plumbing; bench.py builds a process group only for world > 1 or --force-ddp): train.py:107,168
   ( timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline ) > $out/bench_torchrun_one_rank.log 2>&1; grep "^{" $out/bench_torchrun_one_rank.log | cut -c1-300
   ( timeout 600 python bench.py --per-gpu-batch 1 --graph --no-cpu-baseline ) > $out/bench_b1_graph.log 2>&1; grep "^{" $out/bench_b1_graph.log | cut -c1-200
+  # the same bench line from the round-5 tree (.r05/: `git archive` of the round-5 final commit + its library, not tracked) and
+  # from this tree, alternating ON THIS BOX: boxes of the pool differ by 2-3 % in sustained clock, rounds are compared here
+  if [ -d .r05 ]; then
+    : > $out/ab_r05_same_box.txt
+    for rep in 1 2; do
+      for tree in .r05 .; do
+        ( cd $tree && timeout 600 python bench.py --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | grep "^{" | python -c "
+import sys, json
+d = json.loads(sys.stdin.readline())
+print('%-5s rep $rep  %.3f images/s  %.2f ms/step  scan bwd %.1f us  fwd %.1f us' % ('$tree', d['value'], d['ms_per_step'], d['roofline']['avg_launch_us'], d['roofline_fwd']['avg_launch_us']))" ) | tee -a $out/ab_r05_same_box.txt
+      done
+    done
+  fi
   ;;
 extras)
   # measurements beside the headline: forward only (BASELINE configs[1]), sigma_base 720x1280 (configs[4]), the batch-8 step as a
