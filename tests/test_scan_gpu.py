@@ -518,11 +518,24 @@ FULL_LAUNCHES = [
     (8, 768, 19200, 4, 4, 0b1010, 1, 640),
     (8, 384, 38400, 4, 2, 0b10, 1, 640),
     (8, 1536, 4800, 4, 4, 0b1010, 1, 160),
+    # round 6: the REST of the 15 distinct launch shapes of the batch-8 step, so that every scan launch the bench times has
+    # run at its real size against the oracle with the kernels the policy picks for it: encoder stages 1 and 3 (quad-row),
+    # decoder stage 2, ConMB stages 1-3 (64-lane at 9600, quad-row below), CroMB stages 0-3 (one group, plain direction:
+    # Cross_Mamba_Attention_SSM through selective_scan_fn, vmamba.py:1407-1545 -- row-lane where rowlane_pays, quad-row at L = 300)
+    (16, 1536, 4800, 16, 4, 0b1010, 1, 160),
+    (16, 6144, 300, 16, 4, 0b1010, 1, 160),
+    (8, 3072, 1200, 4, 4, 0b1010, 1, 160),
+    (8, 768, 9600, 4, 2, 0b10, 1, 640),
+    (8, 1536, 2400, 4, 2, 0b10, 1, 160),
+    (8, 3072, 600, 4, 2, 0b10, 1, 160),
+    (8, 192, 19200, 4, 1, 0, 0, 16),
+    (8, 384, 4800, 4, 1, 0, 0, 16),
+    (8, 768, 1200, 4, 1, 0, 0, 16),
+    (8, 1536, 300, 4, 1, 0, 0, 160),
 ]
 
 
-@pytest.mark.parametrize("shape", FULL_LAUNCHES, ids=["16x3072x1200xN16", "16x768x19200xN16", "2x3072x1200xN16", "1x768x19200xN16",
-                                                      "8x768x19200xN4", "8x384x38400xN4", "8x1536x4800xN4"])
+@pytest.mark.parametrize("shape", FULL_LAUNCHES, ids=["x".join(map(str, s[:3])) + "xN%d" % s[3] + ("g%d" % s[4] if s[4] != 4 else "") for s in FULL_LAUNCHES])
 def test_full_size_step_launches_against_oracle(shape):
     """The benchmarked launches AT THEIR REAL SIZE, with the pitch / kernels the fused model path (SS2DCoreFn) picks
     automatically -- ckpt_pitch_for called exactly as ss2d_fused calls it, with rowlane_ok of the operands and the group
