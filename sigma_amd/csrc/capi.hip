@@ -527,9 +527,19 @@ PlanR plan_rowlane(const sigma_scan_fwd_params* p, bool vec, bool backward) {
             if (S > 1 && (st < 2 || (long)st * (S - 1) >= ntiles)) continue;      // >= 2 tiles each, none empty
             const long nwg = nwg0 * S;
             const double rounds = (double)((nwg + slots - 1) / slots);
-            double wres = (double)(nwg < slots ? nwg : slots) * nw / (4.0 * kCUs);   // resident waves per SIMD
+            // resident waves per SIMD ON THE BUSIEST CU: a launch that fits one round is as slow as the CUs that hold one
+            // workgroup more than the others -- (1,768,19200) forward with 48 segments = 576 workgroups (three on 64 CUs,
+            // two on the rest) ran 170 us, with 40 segments = 480 (two at most) 149 us (round 6, rl_segs sweeps:
+            // profiles/r06_rowlane_segment_sweep.txt).  A third workgroup on a CU adds 67 % to a tile's time, not 50 %
+            // (64 segments: 8.3 us per tile against 5.0 with two), and every further round costs its tail and refill
+            // ((8,192,19200,N4) backward: 64 segments in three rounds 344 us, 21 in one 284).
+            // The backward keeps the chip-average occupancy: its summary pre-pass costs more per segment, and on the small
+            // one-image shapes fewer, longer segments measured better than an even fill ((1,768,9600,N4): 30 segments 82 us, 40: 88).
+            const long per_cu = nwg <= slots ? (nwg + kCUs - 1) / kCUs : cand[ci].wgpc;
+            double wres = backward ? (double)(nwg < slots ? nwg : slots) * nw / (4.0 * kCUs)
+                                   : (double)per_cu * nw / 4.0 * (per_cu >= 3 ? 1.1 : 1.0);
             if (wres < 1.9) wres = 1.9;                            // a lone wave issues every ~4.5 clocks
-            const double t = rounds * st * wres * ((N / nw) * 16 * ces + fixed) * (S > 1 ? pre : 1.0);
+            const double t = rounds * (rounds > 1.0 ? 1.15 : 1.0) * st * wres * ((N / nw) * 16 * ces + fixed) * (S > 1 ? pre : 1.0);
             if (t < best * 0.999) { best = t; pl.NW = nw; pl.S = S; pl.seg_tiles = st; }
         }
     }

@@ -303,10 +303,25 @@ __device__ __forceinline__ void scan_bwdr_body(const BwdArgs& q, float* smem, co
     if (pc.cin == 1) {
         // reverse carry entering the right end = composition of the summaries of the segments after this one
         const float2* __restrict__ sm = reinterpret_cast<const float2*>(q.summ);
-        for (int t = q.S - 1; t > seg; --t) {
+        // eight summaries requested at once (as in the forward: one iteration per segment waited for its own loads)
+        const long sm_seg = (long)p.batch * (p.dim >> 6) * N * 64;
+        const float2* __restrict__ sm0 = sm + ((long)rowblock * N + n0) * 64 + lane;
+        int t = q.S - 1;
+        for (; t - 8 >= seg; t -= 8) {
+            float2 pe[8][NS];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+#pragma unroll
+                for (int s = 0; s < NS; ++s) pe[k][s] = sm0[(long)(t - 1 - k) * sm_seg + s * 64];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+#pragma unroll
+                for (int s = 0; s < NS; ++s) ecar[s] = fmaf(pe[k][s].x, ecar[s], pe[k][s].y);
+        }
+        for (; t > seg; --t) {
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
-                const float2 pe = sm[(((long)(t - 1) * p.batch * (p.dim >> 6) + rowblock) * N + n0 + s) * 64 + lane];
+                const float2 pe = sm0[(long)(t - 1) * sm_seg + s * 64];
                 ecar[s] = fmaf(pe.x, ecar[s], pe.y);
             }
         }

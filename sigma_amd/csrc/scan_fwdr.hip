@@ -99,10 +99,26 @@ __device__ __forceinline__ void scan_fwdr_body(const FwdArgs& p, float* smem, in
     } else if (p.segs > 1 && seg > 0) {
         // incoming state = composition of the summaries of the segments before this one (scan order)
         const float2* __restrict__ sm = reinterpret_cast<const float2*>(p.fsumm);
-        for (int t = 0; t < seg; ++t) {
+        // eight segments' summaries requested at once: one iteration per segment waited ~0.4 us for its own four loads, and the
+        // LAST segment's workgroup entered its tile loop up to 47 of those late (round 6: (1,768,19200) runs 48 segments)
+        const long sm_seg = (long)p.batch * (p.dim >> 6) * N * 64;
+        const float2* __restrict__ sm0 = sm + ((long)rowblock * N + n0) * 64 + lane;
+        int t = 0;
+        for (; t + 8 <= seg; t += 8) {
+            float2 pe[8][NS];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+#pragma unroll
+                for (int s = 0; s < NS; ++s) pe[k][s] = sm0[(long)(t + k) * sm_seg + s * 64];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+#pragma unroll
+                for (int s = 0; s < NS; ++s) xst[s] = fmaf(pe[k][s].x, xst[s], pe[k][s].y);
+        }
+        for (; t < seg; ++t) {
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
-                const float2 pe = sm[(((long)t * p.batch * (p.dim >> 6) + rowblock) * N + n0 + s) * 64 + lane];
+                const float2 pe = sm0[(long)t * sm_seg + s * 64];
                 xst[s] = fmaf(pe.x, xst[s], pe.y);
             }
         }
@@ -329,10 +345,26 @@ __device__ __forceinline__ void scan_fwdp_body(const FwdArgs& p, float* smem, in
     if (nst <= 0) return;
     if (p.segs > 1 && seg > 0) {
         const float2* __restrict__ sm = reinterpret_cast<const float2*>(p.fsumm);
-        for (int t = 0; t < seg; ++t) {
+        // eight segments' summaries requested at once: one iteration per segment waited ~0.4 us for its own four loads, and the
+        // LAST segment's workgroup entered its tile loop up to 47 of those late (round 6: (1,768,19200) runs 48 segments)
+        const long sm_seg = (long)p.batch * (p.dim >> 6) * N * 64;
+        const float2* __restrict__ sm0 = sm + ((long)rowblock * N + n0) * 64 + lane;
+        int t = 0;
+        for (; t + 8 <= seg; t += 8) {
+            float2 pe[8][NS];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+#pragma unroll
+                for (int s = 0; s < NS; ++s) pe[k][s] = sm0[(long)(t + k) * sm_seg + s * 64];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+#pragma unroll
+                for (int s = 0; s < NS; ++s) xst[s] = fmaf(pe[k][s].x, xst[s], pe[k][s].y);
+        }
+        for (; t < seg; ++t) {
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
-                const float2 pe = sm[(((long)t * p.batch * (p.dim >> 6) + rowblock) * N + n0 + s) * 64 + lane];
+                const float2 pe = sm0[(long)t * sm_seg + s * 64];
                 xst[s] = fmaf(pe.x, xst[s], pe.y);
             }
         }
