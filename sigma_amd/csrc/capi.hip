@@ -537,7 +537,7 @@ PlanR plan_rowlane(const sigma_scan_fwd_params* p, bool vec, bool backward) {
             // one-image shapes fewer, longer segments measured better than an even fill ((1,768,9600,N4): 30 segments 82 us, 40: 88).
             const long per_cu = nwg <= slots ? (nwg + kCUs - 1) / kCUs : cand[ci].wgpc;
             double wres = backward ? (double)(nwg < slots ? nwg : slots) * nw / (4.0 * kCUs)
-                                   : (double)per_cu * nw / 4.0 * (per_cu >= 3 ? 1.1 : 1.0);
+                                   : (double)per_cu * nw / 4.0 * (per_cu >= 3 && N >= 8 ? 1.1 : 1.0);   // 4 states: a lighter wave, the third / fourth workgroup scales
             if (wres < 1.9) wres = 1.9;                            // a lone wave issues every ~4.5 clocks
             const double t = rounds * (rounds > 1.0 ? 1.15 : 1.0) * st * wres * ((N / nw) * 16 * ces + fixed) * (S > 1 ? pre : 1.0);
             if (t < best * 0.999) { best = t; pl.NW = nw; pl.S = S; pl.seg_tiles = st; }
