@@ -101,6 +101,18 @@ def test_options_and_launch_plan():
     assert items in (4, 5, 10, 20) and 1 <= rows <= 16 and 1 <= rows * tiles <= 16 and nb in (1, 2, 4, 8)
     assert (768 // 4) % rows == 0 and grid == 768 // rows and lds <= 160 * 1024
     assert tiles > 1 and grid >= 128          # one image per GPU still fills the chip
+    # the same launch on the row-lane kernels (ckpt_pitch 16): 12 row blocks are cut into segments so that no CU holds a
+    # workgroup more than the others (round 6: 48 segments = 576 workgroups, three on 64 CUs and two on the rest, ran 170 us;
+    # 40-42 segments = 480-504, two at most, 149-152 us) -- and the dominant training launch is not cut at all
+    for b, d, L, n, g in ((1, 768, 19200, 16, 4), (2, 768, 19200, 16, 4), (1, 1536, 4800, 16, 4), (2, 3072, 1200, 16, 4)):
+        pr = _params(batch=b, dim=d, seqlen=L, dstate=n, n_groups=g, n_chunks=(L + 2047) // 2048)
+        pr.ckpt_pitch = 16
+        assert lib.sigma_scan_fwd_plan(ctypes.byref(pr), ctypes.byref(plan)) == 0
+        assert plan[0] == 16 and plan[5] == -200 and plan[4] > 1 and plan[2] == b * (d // 64) * plan[4]
+        assert 384 <= plan[2] <= 512 or plan[2] % 256 == 0, list(plan)
+    pr = _params(batch=16, dim=3072, seqlen=1200, dstate=16, n_groups=4, n_chunks=1)
+    pr.ckpt_pitch = 16
+    assert lib.sigma_scan_fwd_plan(ctypes.byref(pr), ctypes.byref(plan)) == 0 and plan[4] == 1 and plan[2] == 768
     # a training batch has enough rows: no sequence split; long 16-state rows take 1280-element tiles ...
     pb = _params(batch=16, dim=768, seqlen=19200, dstate=16, n_groups=4, n_chunks=10)
     assert lib.sigma_scan_fwd_plan(ctypes.byref(pb), ctypes.byref(plan)) == 0
