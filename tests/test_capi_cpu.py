@@ -156,3 +156,38 @@ def test_operator_module_raises_without_gpu_tensors():
     Bm = torch.randn(1, 1, 4, 16)
     with pytest.raises(RuntimeError, match="GPU tensor"):
         core.fwd(u, u, A, Bm, Bm, None, None, False, 1)
+
+
+def test_gemm_workspace_query_is_host_side_planning():
+    """sigma_gemm_workspace_bytes needs no GPU: the scratch of the two-stage sums follows from the launch geometry --
+    reduction slices x output bytes for a weight gradient (tn), problems per output for shared outputs (c_mod), nothing
+    when every work item owns its output; bad arguments answer -1."""
+    lib = _capi.load()
+
+    def params(M, N, K, lda, ldb, ldc, **kw):
+        p = _capi.GemmParams()
+        p.M, p.N, p.K, p.lda, p.ldb, p.ldc = M, N, K, lda, ldb, ldc
+        p.A, p.Bt, p.C = 0x10000, 0x20000, 0x30000          # never dereferenced by the query (16-byte aligned non-null)
+        p.batch, p.pieces = kw.pop("batch", 1), 2
+        for k, v in kw.items():
+            setattr(p, k, v)
+        return p
+
+    q = lambda p, form: int(lib.sigma_gemm_workspace_bytes(ctypes.byref(p), form))
+    # forward / input gradient of a linear layer: every tile owns its output
+    assert q(params(19200, 1536, 384, 384, 384, 1536), 0) == 0
+    assert q(params(19200, 384, 1536, 1536, 384, 384), 1) == 0
+    # weight gradient of the stage-2 in_proj (19200 tokens, 1536 x 384): 36 tiles -> 14 slices in one round of 512 workgroups
+    assert q(params(19200, 1536, 384, 1536, 384, 384), 2) == 14 * 1536 * 384 * 4
+    # few tokens: one slice, no scratch
+    assert q(params(200, 72, 44, 72, 44, 44), 2) == 0
+    # the sliced nn form (dW_x = dx^T x with dx channel-major): 768 x 384 output, 19200-long reduction
+    need = q(params(768, 384, 19200, 19200, 384, 384, k_slices=1), 1)
+    assert need > 0 and need % (768 * 384 * 4) == 0 and need // (768 * 384 * 4) <= 512 // 18
+    # shared outputs: 32 problems summed into 2 outputs of 112 x 768 -> 16 parts per output
+    sh = params(112, 768, 1200, 1200, 1200, 768, batch=32, c_mod=2, strideA=112 * 1200, strideB=768 * 1200, strideC=112 * 768, accumulate=1)
+    assert q(sh, 0) == 2 * 16 * 112 * 768 * 4
+    # bad arguments
+    assert q(params(19200, 1536, 384, 384, 384, 1536), 7) == -1
+    bad = params(19200, 1536, 383, 384, 384, 1536)
+    assert q(bad, 0) == -1
